@@ -1,0 +1,64 @@
+// ldpc_hip.h -- device-side LDPC decoder object behind the C ABI (include/dvbs2_fec_hip.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <string>
+#include "ldpc_schedule.h"
+
+namespace dvbs2 {
+
+class LdpcDecoderHip {
+public:
+    // group_size G: frames [G*g, G*g+G) share one iteration count, exactly like one SIMD batch of the
+    // reference (lib/ldpc_decoder_bb_impl.cc:406-410, lib/ldpc_decoder/layered_decoder.hh:153). G = 1
+    // stops every frame on its own.
+    LdpcDecoderHip(const LdpcTableDesc* table, int out_bits_message, int group_size, int max_frames, int device);
+    ~LdpcDecoderHip();
+    bool ok() const { return err_.empty(); }
+    const std::string& error() const { return err_; }
+
+    int N() const { return sched_.N; }
+    int K() const { return sched_.K; }
+    int q() const { return sched_.q; }
+    int out_bits_message() const { return out_bits_message_; }
+    int group_size() const { return G_; }
+    int max_frames() const { return max_frames_; }
+    const LdpcSchedule& schedule() const { return sched_; }
+
+    // All pointers are DEVICE pointers. d_llr_in: n_frames*N int8 (frame-major, positive = bit 0).
+    // d_bits_out: n_frames * (out_mode ? out_bits_message/8 : N/8) bytes, MSB first.
+    // d_llr_out (nullable): n_frames*N decoded LLRs (what the reference publishes as llr_pdu).
+    // d_ret (nullable): one int32 per group = the reference decode() return value (trials left, or -1).
+    // Enqueues on `stream` and synchronises it before returning (the group logic needs one flag read).
+    int decode_device(const int8_t* d_llr_in, int n_frames, int max_trials, int out_mode,
+                      uint8_t* d_bits_out, int8_t* d_llr_out, int32_t* d_ret, hipStream_t stream);
+
+    // average duration (ms) and launch count of the main update kernel since the last reset (HIP events
+    // on the launch stream; only recorded when profiling is enabled).
+    void set_profiling(bool on) { profiling_ = on; }
+    void reset_profile() { prof_ms_ = 0; prof_launches_ = 0; }
+    double profile_ms() const { return prof_ms_; }
+    int profile_launches() const { return prof_launches_; }
+
+private:
+    LdpcSchedule sched_;
+    int out_bits_message_, G_, max_frames_, device_;
+    int words_per_check_ = 0; // message dwords per check (4 int8 messages per dword)
+    int dmax_ = 0;            // kernel variant: max check degree handled (8, 16 or 32)
+    uint32_t* d_layers_ = nullptr;
+    uint32_t* d_entries_ = nullptr;
+    uint8_t* d_state_ = nullptr;  // max_frames * N, internal layout, offset-binary LLRs
+    uint32_t* d_msgs_ = nullptr;  // max_frames * q * words_per_check * 384
+    int* d_iters_ = nullptr;      // per frame: updates done
+    int* d_good_ = nullptr;       // per frame: syndrome satisfied at the current state
+    int* d_target_ = nullptr;     // per frame: updates to reach in a resume pass
+    int* d_flag_ = nullptr;       // [0] = number of unresolved groups
+    int* h_flag_ = nullptr;       // pinned
+    bool profiling_ = false;
+    double prof_ms_ = 0;
+    int prof_launches_ = 0;
+    hipEvent_t ev0_ = nullptr, ev1_ = nullptr;
+    std::string err_;
+};
+
+} // namespace dvbs2

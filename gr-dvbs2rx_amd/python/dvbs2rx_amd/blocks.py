@@ -1,0 +1,121 @@
+"""Python view of the three reference blocks' compute, calling the C ABI.
+
+Names and argument meaning follow the reference block constructors:
+  ldpc_decoder_bb.make(standard, framesize, rate, constellation, outputmode, infomode, max_trials, debug_level)
+      include/gnuradio/dvbs2rx/ldpc_decoder_bb.h:37-44
+The Python classes exist for the tests and the benchmark; the production drop-in is the C++ shim
+in INTEGRATION.md that calls the same C entry points from the blocks' general_work().
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+from .capi import lib, check
+
+__all__ = ["get_fec_info", "rate_id", "LdpcDecoder", "ldpc_table_info", "ldpc_layer_info"]
+
+DEFAULT_TRIALS = 25  # reference lib/ldpc_decoder_bb_impl.cc:391
+
+
+def rate_id(rate):
+    if isinstance(rate, str):
+        r = lib.dvbs2_rate_from_name(rate.encode())
+        if r < 0:
+            raise ValueError(f"unknown code rate {rate}")
+        return r
+    return int(rate)
+
+
+def get_fec_info(standard, framesize, rate):
+    fi = capi.FecInfo()
+    check(lib.dvbs2_get_fec_info(standard, framesize, rate_id(rate), fi))
+    return dict(bch_k=fi.bch_k, bch_n=fi.bch_n, bch_t=fi.bch_t, ldpc_k=fi.ldpc_k, ldpc_n=fi.ldpc_n,
+                table_k=fi.table_k, table=fi.table.decode())
+
+
+def ldpc_table_info(table):
+    v = [C.c_int() for _ in range(5)]
+    check(lib.dvbs2_ldpc_table_info(table.encode(), *v))
+    return dict(zip(("N", "K", "q", "links_total", "conflict_layers"), (x.value for x in v)))
+
+
+def ldpc_layer_info(table, layer):
+    g = np.zeros(64, np.int32)
+    s = np.zeros(64, np.int32)
+    blk = C.c_int()
+    cnt = check(lib.dvbs2_ldpc_layer_info(table.encode(), layer, blk, g.ctypes.data, s.ctypes.data, 64))
+    return dict(cnt=cnt, block=blk.value, groups=g[:cnt].tolist(), shifts=s[:cnt].tolist())
+
+
+class LdpcDecoder:
+    """ldpc_decoder_bb's compute: batches of int8 LLR frames -> packed hard bits (+ decoded LLRs)."""
+
+    def __init__(self, standard=capi.STANDARD_DVBS2, framesize=capi.FECFRAME_NORMAL, rate="C1_2",
+                 outputmode=capi.OM_MESSAGE, max_trials=0, group_size=32, max_frames=64, device=0,
+                 table=None, message_bits=None):
+        self._h = C.c_void_p()
+        if table is not None:
+            check(lib.dvbs2_ldpc_create_table(C.byref(self._h), table.encode(), int(message_bits),
+                                              group_size, max_frames, device))
+        else:
+            check(lib.dvbs2_ldpc_create(C.byref(self._h), standard, framesize, rate_id(rate),
+                                        group_size, max_frames, device))
+        v = [C.c_int() for _ in range(5)]
+        check(lib.dvbs2_ldpc_params(self._h, *v))
+        self.N, self.K, self.message_bits, self.q, self.group_size = (x.value for x in v)
+        self.outputmode = outputmode
+        self.max_trials = DEFAULT_TRIALS if max_trials == 0 else max_trials
+        self.max_frames = max_frames
+        # counters behind get_average_trials() (reference lib/ldpc_decoder_bb_impl.h:63, .cc:411-419)
+        self.total_trials = 0
+        self.batch_cnt = 0
+        self.frame_cnt = 0
+
+    def close(self):
+        if self._h:
+            lib.dvbs2_ldpc_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def out_bytes(self):
+        return (self.message_bits if self.outputmode == capi.OM_MESSAGE else self.N) // 8
+
+    def _account(self, ret):
+        for r in ret:
+            self.total_trials += self.max_trials if r < 0 else self.max_trials - int(r)
+            self.batch_cnt += 1
+
+    def get_average_trials(self):
+        return self.total_trials // self.batch_cnt
+
+    def work(self, llr, want_llr=False):
+        """llr: (n_frames, N) int8 host array. Returns (bits (n_frames, out_bytes) uint8, llr_out or None, ret per group)."""
+        llr = np.ascontiguousarray(llr, dtype=np.int8)
+        nf = llr.shape[0]
+        assert llr.shape == (nf, self.N)
+        bits = np.empty((nf, self.out_bytes), np.uint8)
+        out = np.empty((nf, self.N), np.int8) if want_llr else None
+        ng = (nf + self.group_size - 1) // self.group_size
+        ret = np.empty(ng, np.int32)
+        check(lib.dvbs2_ldpc_decode(self._h, llr.ctypes.data, nf, self.max_trials, self.outputmode,
+                                    bits.ctypes.data, out.ctypes.data if want_llr else None, ret.ctypes.data))
+        self._account(ret)
+        self.frame_cnt += nf
+        return bits, out, ret
+
+    def work_device(self, d_llr, n_frames, d_bits, d_llr_out=0, d_ret=0, stream=0):
+        """Device-pointer variant (ints from torch.Tensor.data_ptr()); stream = raw hipStream_t value."""
+        check(lib.dvbs2_ldpc_decode_device(self._h, d_llr, n_frames, self.max_trials, self.outputmode,
+                                           d_bits, d_llr_out or None, d_ret or None, stream or None))
+
+    def profile(self, enable=True):
+        ms, n = C.c_double(), C.c_int()
+        check(lib.dvbs2_ldpc_profile(self._h, 1 if enable else 0, ms, n))
+        return ms.value, n.value

@@ -1,0 +1,64 @@
+"""ctypes binding of libdvbs2_fec_hip.so (include/dvbs2_fec_hip.h).
+
+This is the stub a maintainer of the reference would bind (see INTEGRATION.md for the C++ side);
+the tests and bench.py drive the C ABI through it. There is deliberately no fallback: if the
+shared library is missing, import of this module raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.normpath(os.path.join(_HERE, "..", "..", "lib", "libdvbs2_fec_hip.so"))
+
+OK, EINVAL, EDEVICE, ESIZE = 0, -1, -2, -3
+STANDARD_DVBS2, STANDARD_DVBT2 = 0, 1
+FECFRAME_SHORT, FECFRAME_NORMAL, FECFRAME_MEDIUM = 0, 1, 2
+OM_CODEWORD, OM_MESSAGE = 0, 1
+MOD_QPSK, MOD_8PSK = 0, 2
+
+
+class FecInfo(C.Structure):
+    _fields_ = [("bch_k", C.c_uint32), ("bch_n", C.c_uint32), ("bch_t", C.c_uint32),
+                ("ldpc_k", C.c_uint32), ("ldpc_n", C.c_uint32), ("table_k", C.c_uint32),
+                ("table", C.c_char * 24)]
+
+
+# every symbol include/dvbs2_fec_hip.h declares: name -> (restype, argtypes)
+_vp, _i, _ip = C.c_void_p, C.c_int, C.POINTER(C.c_int)
+SYMBOLS = {
+    "dvbs2_last_error": (C.c_char_p, []),
+    "dvbs2_device_count": (_i, []),
+    "dvbs2_get_fec_info": (_i, [_i, _i, _i, C.POINTER(FecInfo)]),
+    "dvbs2_rate_name": (C.c_char_p, [_i]),
+    "dvbs2_rate_from_name": (_i, [C.c_char_p]),
+    "dvbs2_ldpc_table_info": (_i, [C.c_char_p, _ip, _ip, _ip, _ip, _ip]),
+    "dvbs2_ldpc_layer_info": (_i, [C.c_char_p, _i, _ip, _vp, _vp, _i]),
+    "dvbs2_ldpc_create": (_i, [C.POINTER(_vp), _i, _i, _i, _i, _i, _i]),
+    "dvbs2_ldpc_create_table": (_i, [C.POINTER(_vp), C.c_char_p, _i, _i, _i, _i]),
+    "dvbs2_ldpc_destroy": (None, [_vp]),
+    "dvbs2_ldpc_params": (_i, [_vp, _ip, _ip, _ip, _ip, _ip]),
+    "dvbs2_ldpc_decode": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "dvbs2_ldpc_decode_device": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "dvbs2_ldpc_profile": (_i, [_vp, _i, C.POINTER(C.c_double), _ip]),
+}
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(f"{LIB_PATH} not found: build it with `make -C gr-dvbs2rx_amd` "
+                      "(or __graft_entry__.build()); there is no CPU fallback")
+lib = C.CDLL(LIB_PATH)
+for _name, (_res, _args) in SYMBOLS.items():
+    _f = getattr(lib, _name)
+    _f.restype = _res
+    _f.argtypes = _args
+
+
+class Dvbs2Error(RuntimeError):
+    def __init__(self, code):
+        self.code = code
+        super().__init__(f"libdvbs2_fec_hip error {code}: {lib.dvbs2_last_error().decode()}")
+
+
+def check(code):
+    if code < 0:
+        raise Dvbs2Error(code)
+    return code

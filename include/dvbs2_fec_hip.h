@@ -1,0 +1,103 @@
+/*
+ * dvbs2_fec_hip.h -- C ABI of libdvbs2_fec_hip.so: the MI355X (gfx950) DVB-S2/S2X FEC decode path
+ * (soft demapper -> layered LDPC -> BCH) as a drop-in for the compute inside the reference's three
+ * GNU Radio blocks. Plain pointers and sizes only; no C++ exceptions cross this boundary; every
+ * object is a handle (re-entrant across block instances, unlike the reference's global per-TU
+ * LdpcDecoder, lib/ldpc_decoder/ldpc_decoder_avx2.cc:21). One caller thread per handle at a time
+ * (GNU Radio calls a block's general_work from exactly one thread).
+ *
+ * Enumerations take the integer values of the reference's include/gnuradio/dvbs2rx/dvb_config.h
+ * (dvb_standard_t :15-18, dvb_code_rate_t :20-72, dvb_framesize_t :74-78, dvb_constellation_t :80-101,
+ * dvb_outputmode_t :113-116), so the blocks can pass their constructor arguments through unchanged.
+ *
+ * All functions return DVBS2_OK (0) or a negative DVBS2_E* code; dvbs2_last_error() gives the text.
+ * "_device" variants take DEVICE pointers (HBM-resident buffers) and a hipStream_t passed as void*;
+ * the plain variants take HOST pointers and stage through buffers owned by the handle.
+ * There is no CPU fallback: without a usable HIP device the create calls fail with DVBS2_EDEVICE.
+ */
+#ifndef DVBS2_FEC_HIP_H
+#define DVBS2_FEC_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DVBS2_OK 0
+#define DVBS2_EINVAL (-1)   /* bad argument / unsupported (standard, framesize, rate) */
+#define DVBS2_EDEVICE (-2)  /* HIP error or no device */
+#define DVBS2_ESIZE (-3)    /* n_frames exceeds the handle's max_frames */
+
+/* dvb_standard_t */
+#define DVBS2_STANDARD_DVBS2 0
+#define DVBS2_STANDARD_DVBT2 1
+/* dvb_framesize_t */
+#define DVBS2_FECFRAME_SHORT 0
+#define DVBS2_FECFRAME_NORMAL 1
+#define DVBS2_FECFRAME_MEDIUM 2
+/* dvb_outputmode_t */
+#define DVBS2_OM_CODEWORD 0
+#define DVBS2_OM_MESSAGE 1
+/* dvb_constellation_t (only the two the reference demapper supports,
+ * lib/xfecframe_demapper_cb_impl.cc:45-72) */
+#define DVBS2_MOD_QPSK 0
+#define DVBS2_MOD_8PSK 2
+
+const char* dvbs2_last_error(void);
+int dvbs2_device_count(void);
+
+/* ---- parameter map: replaces get_fec_info(), reference lib/fec_params.h:36-39 / fec_params.cc:16-344,
+ * plus the table selection of lib/ldpc_decoder_bb_impl.cc:104-307 ---- */
+typedef struct {
+    uint32_t bch_k, bch_n, bch_t; /* fec_info_t::bch */
+    uint32_t ldpc_k, ldpc_n;      /* fec_info_t::ldpc (ldpc_k == bch_n) */
+    uint32_t table_k;             /* K of the LDPC parity table actually used */
+    char table[24];               /* e.g. "S2_TABLE_B4" */
+} dvbs2_fec_info_t;
+int dvbs2_get_fec_info(int standard, int framesize, int rate, dvbs2_fec_info_t* out);
+/* rate enumerator name ("C1_2", ...) or NULL; dvbs2_rate_from_name returns -1 when unknown */
+const char* dvbs2_rate_name(int rate);
+int dvbs2_rate_from_name(const char* name);
+
+/* ---- LDPC schedule introspection (host only, no device needed): the (group, shift) entries of one
+ * layer as derived from the accumulator-address table; used by the tests of the schedule compiler.
+ * Returns the number of data entries of the layer (<0 on error). groups/shifts may be NULL. ---- */
+int dvbs2_ldpc_table_info(const char* table, int* n, int* k, int* q, int* links_total, int* conflict_layers);
+int dvbs2_ldpc_layer_info(const char* table, int layer, int* block, int* groups, int* shifts, int max_entries);
+
+/* ---- LDPC: replaces ldpc_*::ldpc_dec_init + ldpc_*::ldpc_dec_decode as called by
+ * ldpc_decoder_bb_impl (reference lib/ldpc_decoder_bb_impl.cc:34-52, :320-347, :406-442) ----
+ * group_size G = frames that share one iteration count = the reference's d_simd_size (32 with AVX2,
+ * 16 otherwise, :312-345); frames [G*g, G*g+G) form group g. G = 1 decodes every frame on its own. */
+typedef struct dvbs2_ldpc dvbs2_ldpc_t;
+int dvbs2_ldpc_create(dvbs2_ldpc_t** h, int standard, int framesize, int rate,
+                      int group_size, int max_frames, int device);
+/* same, selecting a parity table by name; message_bits = bits emitted in DVBS2_OM_MESSAGE mode */
+int dvbs2_ldpc_create_table(dvbs2_ldpc_t** h, const char* table, int message_bits,
+                            int group_size, int max_frames, int device);
+void dvbs2_ldpc_destroy(dvbs2_ldpc_t* h);
+int dvbs2_ldpc_params(const dvbs2_ldpc_t* h, int* n, int* table_k, int* message_bits, int* q, int* group_size);
+/*
+ * llr_in       n_frames * N int8, frame-major, positive = bit 0 (the block's input stream, :407)
+ * max_trials   iteration cap (> 0; the block maps 0 to 25 before calling, :391,402)
+ * out_mode     DVBS2_OM_MESSAGE -> message_bits/8 bytes per frame, DVBS2_OM_CODEWORD -> N/8 (:404)
+ * bits_out     hard decisions, MSB first (:432-442)
+ * llr_out      NULL or n_frames * N decoded LLRs (the llr_pdu payload, :422-429)
+ * ret          NULL or one int32 per group: what decode() returned for that batch -- trials left
+ *              (max_trials - updates), or -1 when the cap was hit without convergence (:410-419)
+ * n_frames need not be a multiple of G; a trailing partial group is a group of its own.
+ */
+int dvbs2_ldpc_decode(dvbs2_ldpc_t* h, const int8_t* llr_in, int n_frames, int max_trials, int out_mode,
+                      uint8_t* bits_out, int8_t* llr_out, int32_t* ret);
+int dvbs2_ldpc_decode_device(dvbs2_ldpc_t* h, const int8_t* d_llr_in, int n_frames, int max_trials,
+                             int out_mode, uint8_t* d_bits_out, int8_t* d_llr_out, int32_t* d_ret,
+                             void* stream);
+/* HIP-event timing of the dominant kernel (the layered update sweep) on its launch stream.
+ * enable != 0 starts/reset accumulation; reads back total milliseconds and launch count. */
+int dvbs2_ldpc_profile(dvbs2_ldpc_t* h, int enable, double* total_ms, int* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DVBS2_FEC_HIP_H */

@@ -1,0 +1,117 @@
+"""GPU parity: libdvbs2_fec_hip LDPC (through the C ABI) vs the CPU checkers, bit-exact on decoded LLRs,
+packed bits and per-group return values. Checkers: oracle/liboracle.so (plain-C restatement) and, when the
+prebuilt oracle/_ref travelled with the repo, the genuine reference decoders (AVX2 batch = 32 frames,
+generic batch = 16 frames)."""
+import numpy as np
+import pytest
+
+import fec_testlib as T
+from dvbs2rx_amd import LdpcDecoder, capi
+
+pytestmark = pytest.mark.gpu
+
+
+def checker(table, llr, G, trials):
+    """Genuine reference when it exists for this G, else the restatement."""
+    r = T.ref_ldpc()
+    if r is not None and G in (16, 32):
+        return T.ref_ldpc_decode(table, llr, 0 if G == 32 else 2, trials)
+    return T.oracle_ldpc_decode(table, llr, G, trials)
+
+
+def run_gpu(table, llr, G, trials, outputmode=capi.OM_CODEWORD, message_bits=None):
+    N, K, _, _ = T.ldpc_info(table)
+    dec = LdpcDecoder(table=table, message_bits=message_bits or K, group_size=G, max_frames=llr.shape[0],
+                      max_trials=trials, outputmode=outputmode)
+    bits, out, ret = dec.work(llr, want_llr=True)
+    dec.close()
+    return bits, out, ret
+
+
+def compare(table, llr, G, trials):
+    N, K, _, _ = T.ldpc_info(table)
+    bits, out, ret = run_gpu(table, llr, G, trials)
+    want, wret = checker(table, llr, G, trials)
+    assert ret.tolist() == wret, (table, G)
+    bad = np.nonzero((out != want).any(axis=1))[0]
+    assert bad.size == 0, f"{table} G={G}: LLR mismatch in frames {bad[:8]}"
+    assert np.array_equal(bits, T.pack_bits(want, N))
+    return ret
+
+
+@pytest.mark.parametrize("table,trials", [("S2_TABLE_C1", 25), ("S2_TABLE_B4", 6), ("S2_TABLE_B7", 4),
+                                          ("S2_TABLE_B11", 4), ("S2X_TABLE_B21", 4), ("S2X_TABLE_C8", 6),
+                                          ("S2_TABLE_C10", 5), ("T2_TABLE_A3", 4)])
+def test_never_converging(table, trials):
+    N = T.ldpc_info(table)[0]
+    ret = compare(table, T.llr_noise(32, N, 12345), 32, trials)
+    assert ret.tolist() == [-1]
+
+
+@pytest.mark.parametrize("table,amp,sigma", [("S2_TABLE_B4", 6, 5.2), ("S2_TABLE_B7", 8, 3.6),
+                                             ("S2_TABLE_B11", 10, 2.75), ("S2_TABLE_C1", 5, 6.5),
+                                             ("S2X_TABLE_B21", 10, 3.35)])
+@pytest.mark.parametrize("G", [32, 16])
+def test_near_threshold_groups(table, amp, sigma, G):
+    """Frames converge after different numbers of updates: exercises the batch-coupled stopping rule."""
+    llr, _ = T.llr_codeword_awgn(table, 64, 99, amp=amp, sigma=sigma)
+    ret = compare(table, llr, G, 50)
+    assert len(ret) == 64 // G
+
+
+def test_group_of_one_and_tail():
+    table = "S2_TABLE_C1"
+    llr, _ = T.llr_codeword_awgn(table, 40, 5, amp=5, sigma=6.5)
+    compare(table, llr, 1, 30)
+    # 40 frames with G = 32: trailing group of 8 frames is a group of its own
+    bits, out, ret = run_gpu(table, llr, 32, 30)
+    a, ra = T.oracle_ldpc_decode(table, llr[:32], 32, 30)
+    b, rb = T.oracle_ldpc_decode(table, llr[32:], 8, 30)
+    assert ret.tolist() == ra + rb
+    assert np.array_equal(out, np.concatenate([a, b]))
+
+
+def test_saturation_and_zero_llrs():
+    table = "S2_TABLE_C4"
+    N, K, _, _ = T.ldpc_info(table)
+    rng = np.random.default_rng(3)
+    sat = rng.choice(np.array([-128, -127, 127, 126, 0], np.int8), (32, N))
+    compare(table, sat, 32, 8)
+    compare(table, np.zeros((32, N), np.int8), 32, 3)
+    cw_llr, _ = T.llr_codeword_awgn(table, 32, 4, amp=127, sigma=0.0)
+    ret = compare(table, cw_llr, 32, 10)
+    assert ret.tolist() == [10]  # clean codewords: zero updates
+
+
+def test_output_modes_and_counters():
+    table = "S2_TABLE_B4"
+    N, K, _, _ = T.ldpc_info(table)
+    llr, cw = T.llr_codeword_awgn(table, 32, 8, amp=8, sigma=3.0)
+    dec = LdpcDecoder(rate="C1_2", framesize=capi.FECFRAME_NORMAL, group_size=32, max_frames=32,
+                      max_trials=0, outputmode=capi.OM_MESSAGE)
+    assert (dec.N, dec.K, dec.message_bits, dec.max_trials) == (64800, 32400, 32400, 25)
+    bits, _, ret = dec.work(llr)
+    assert bits.shape == (32, 4050)
+    assert np.array_equal(np.unpackbits(bits, axis=1), cw[:, :K])
+    assert dec.get_average_trials() == 25 - ret[0]
+    dec.close()
+
+
+def test_device_pointer_entry():
+    import torch
+    table = "S2_TABLE_C1"
+    N, K, _, _ = T.ldpc_info(table)
+    llr = T.llr_noise(64, N, 77)
+    dec = LdpcDecoder(table=table, message_bits=K, group_size=32, max_frames=64, max_trials=10,
+                      outputmode=capi.OM_MESSAGE)
+    d_in = torch.from_numpy(llr).cuda()
+    d_bits = torch.empty((64, K // 8), dtype=torch.uint8, device="cuda")
+    d_llr = torch.empty((64, N), dtype=torch.int8, device="cuda")
+    d_ret = torch.empty(2, dtype=torch.int32, device="cuda")
+    dec.work_device(d_in.data_ptr(), 64, d_bits.data_ptr(), d_llr.data_ptr(), d_ret.data_ptr(),
+                    torch.cuda.current_stream().cuda_stream)
+    want, wret = T.oracle_ldpc_decode(table, llr, 32, 10)
+    assert d_ret.cpu().tolist() == wret
+    assert np.array_equal(d_llr.cpu().numpy(), want)
+    assert np.array_equal(d_bits.cpu().numpy(), T.pack_bits(want, K))
+    dec.close()
