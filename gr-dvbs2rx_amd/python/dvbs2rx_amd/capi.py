@@ -7,6 +7,15 @@ shared library is missing, import of this module raises.
 import ctypes as C
 import os
 
+# One HIP runtime per process: PyTorch-ROCm ships its own libamdhip64.so (SONAME libamdhip64.so.7) and
+# resolves it by file name, so it must be loaded BEFORE this library, whose NEEDED libamdhip64.so.7
+# then binds to the already-loaded copy. Loading in the other order puts two HIP/HSA runtimes in the
+# process and the second one finds no GPU. torch is plumbing here (device buffers, streams, RCCL).
+try:
+    import torch  # noqa: F401
+except ImportError:  # standalone use (e.g. from the GNU Radio blocks): the system ROCm runtime is used
+    pass
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.normpath(os.path.join(_HERE, "..", "..", "lib", "libdvbs2_fec_hip.so"))
 
