@@ -44,9 +44,10 @@ private:
     LdpcSchedule sched_;
     int out_bits_message_, G_, max_frames_, device_;
     int words_per_check_ = 0; // message dwords per check (4 int8 messages per dword)
-    int dmax_ = 0;            // kernel variant: max check degree handled (8, 16 or 32)
-    uint32_t* d_layers_ = nullptr;
-    uint32_t* d_entries_ = nullptr;
+    int dmax_ = 0;            // kernel variant: handles check degrees dmax-7 .. dmax (8, 12, ..., 32)
+    uint32_t* d_recs_ = nullptr;  // per-layer records (ldpc_hip.hip)
+    size_t lds_bytes_ = 0;
+    unsigned long long* d_tdbg_ = nullptr; // DVBS2_TIMING=1: per-wave cycle-counter breakdown (diagnostics)
     uint8_t* d_state_ = nullptr;  // max_frames * N, internal layout, offset-binary LLRs
     uint32_t* d_msgs_ = nullptr;  // max_frames * q * words_per_check * 384
     int* d_iters_ = nullptr;      // per frame: updates done

@@ -18,6 +18,7 @@
 #include "ldpc_hip.h"
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 namespace dvbs2 {
@@ -25,153 +26,296 @@ namespace dvbs2 {
 #define HIP_OK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { err_ = std::string(#x) + ": " + hipGetErrorString(e_); return; } } while (0)
 #define HIP_RET(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { err_ = std::string(#x) + ": " + hipGetErrorString(e_); return -1; } } while (0)
 
-constexpr int kThreads = 384; // 6 wavefronts; lanes 0..359 own the 360 rows of a circulant
+// Thread mapping: a workgroup of 12 wavefronts decodes a PAIR of FECFRAMEs in lockstep; wavefronts 0-5 own
+// frame 2b, wavefronts 6-11 own frame 2b+1. Inside a half, thread t (< 360) owns check row t of every
+// circulant layer. Two frames are what the 160 KB of LDS hold (2 x (64800 + 9360) bytes for normal frames);
+// putting them in ONE workgroup makes the hardware spread its 12 waves 3 per SIMD, all in the same phase of
+// the same layer, so the per-layer barrier costs no load-imbalance wait (two independent 6-wave workgroups
+// land 2,2,1,1 on the SIMDs and spend a quarter of their time waiting for the doubly loaded ones).
+constexpr int kHalf = 384;          // threads per frame (6 wavefronts; threads 0..359 active)
+constexpr int kThreads = 2 * kHalf; // 12 wavefronts
 constexpr int kM = 360;
+constexpr int kMsgStride = 384;     // message slots per (layer, word)
+constexpr int kSvWords = 13;        // sign-vector dwords per 360-bit group (360 bits + 32-bit wrap extension)
 
-struct LdpcKernelArgs {
-    const uint32_t* layers;  // per layer: entry_off, cnt | block << 16
-    const uint32_t* entries; // base | rot << 16
-    const int8_t* llr_in;    // fresh frames (natural order) or nullptr when resuming
-    uint8_t* state;          // internal layout, offset binary
-    uint32_t* msgs;
-    int* iters;              // per frame, in/out
-    int* good;               // per frame, out
-    const int* target;       // per frame (resume) or nullptr (use cap)
-    int N, K, q, wpc, cap, stop_on_good;
-};
+// Layer record (uniform data, read with scalar loads): RS = 2*DMAX + 4 dwords.
+//   word 0: cnt | sync_before << 15 | block << 16
+//   words 4+2k, 5+2k (k < deg): entry k as  S0 = 360*g + rot  and  thr = 360 - rot
+// Entry k addresses the LDS window [360*g, 360*g + 360) rotated by rot: check row j touches byte
+// 360*g + (j + rot) mod 360 = (j < thr ? S0 + j : S0 + j - 360).
+__host__ __device__ constexpr int rec_stride(int dmax) { return 2 * dmax + 4; }
+__host__ __device__ constexpr size_t half_lds_bytes(int N) { return ((size_t)N + (size_t)(N / kM) * kSvWords * 4 + 32 + 15) / 16 * 16; }
 
-template <int DMAX>
-__global__ __launch_bounds__(kThreads) void ldpc_layered_kernel(LdpcKernelArgs a)
+__device__ __forceinline__ int wrap360(int t) { return t >= kM ? t - kM : t; }
+
+// One check node (layered_decoder.hh:56-77 + algorithms.hh:170-192,203-206), fully unrolled for its degree.
+// LLRs are offset-binary bytes Lb = L + 128 in LDS; messages are offset-binary bytes, 4 per dword.
+// The kernel is VALU-issue bound (not HBM bound): ~22 VALU + 2 LDS instructions per edge.
+template <int DEG, bool LAYER0>
+__device__ __forceinline__ void check_node(uint8_t* __restrict__ lds, const uint32_t* ent /*uniform: S0, thr pairs*/,
+                                           int jj, const uint32_t* mw, uint32_t* nm)
 {
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    const int f = blockIdx.x;
-    const int tid = threadIdx.x;
-    const int N = a.N, K = a.K, q = a.q;
-
-    int it;
-    const int tgt = a.target ? a.target[f] : a.cap;
-    if (a.llr_in) {
-        it = 0;
-        const int8_t* src = a.llr_in + (size_t)f * N;
-        for (int n = tid; n < N; n += kThreads) {
-            uint8_t v = (uint8_t)src[n] ^ 0x80u;
-            if (n < K) lds[n] = v;
-            else { int r = n - K; lds[K + kM * (r % q) + r / q] = v; } // pty[360*i+j] = parity[q*j+i]
-        }
-    } else {
-        it = a.iters[f];
-        if (it >= tgt) return; // nothing to do for this frame in this pass (uniform)
-        const uint8_t* src = a.state + (size_t)f * N;
-        for (int n = tid; n < N; n += kThreads) lds[n] = src[n];
+    int ad[DEG], Lb[DEG];
+#pragma unroll
+    for (int k = 0; k < DEG; k++) {
+        const int t0 = jj + (int)ent[2 * k];
+        ad[k] = (uint32_t)jj < ent[2 * k + 1] ? t0 : t0 - kM;
     }
-    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < DEG; k++) Lb[k] = lds[ad[k]];
+    // check (0,0) has no previous-parity link (layered_decoder.hh:56,63-66)
+    const bool last_valid = !LAYER0 || jj != 0;
 
-    uint32_t* msg_base = a.msgs + (size_t)f * q * a.wpc * kThreads;
-    const int j = tid;
-    bool good = false;
+    int inp[DEG], mg[DEG];
+    int min0 = 127, min1 = 127, signs = 0;
+#pragma unroll
+    for (int k = 0; k < DEG; k++) {
+        const int mb = (int)((mw[k >> 2] >> (8 * (k & 3))) & 0xffu);
+        // R1 inp = sat8(L - m); R2 mag = usat(qabs(inp) - 1) == med3(|L - m| - 1, 0, 126)
+        int d = min(max(Lb[k] - mb, -128), 127);
+        int mag = (int)__builtin_amdgcn_sad_u16((uint32_t)Lb[k], (uint32_t)mb, 0xffffffffu);
+        mag = min(max(mag, 0), 126);
+        if (LAYER0 && k == DEG - 1) { d = last_valid ? d : 0; mag = last_valid ? mag : 127; }
+        inp[k] = d; mg[k] = mag;
+        // R3 two smallest magnitudes (new min1 = median(min0, min1, mag)); R4 xor of the sign bits
+        min1 = min(max(mag, min0), min1);
+        min0 = min(min0, mag);
+        signs ^= d;
+    }
+#pragma unroll
+    for (int w = 0; w < (DEG + 3) / 4; w++) nm[w] = 0;
+#pragma unroll
+    for (int k = 0; k < DEG; k++) {
+        // R5 out = vsign(mag == min0 ? min1 : min0, (signs ^ x) | 127)
+        const int other = (mg[k] == min0) ? min1 : min0;
+        const int sg = (signs ^ inp[k]) >> 31;
+        const int out = (other ^ sg) - sg;
+        // R6 LLR = sat8(inp + out) with the unclamped out; R7 stored message = clamp(out, -32, 31)
+        const int nl = min(max(inp[k] + out + 128, 0), 255);
+        if (!(LAYER0 && k == DEG - 1) || last_valid) lds[ad[k]] = (uint8_t)nl;
+        const int nmsg = min(max(out, -32), 31) + 128;
+        nm[k >> 2] |= (uint32_t)nmsg << (8 * (k & 3));
+    }
+}
+
+// degrees DMAX-7 .. DMAX are instantiated for kernel variant DMAX
+#define DVBS2_DEG_CASE(D) case D: if constexpr (D >= 3 && D <= DMAX && D > DMAX - 8) { \
+        if (layer0) check_node<(D >= 3 ? D : 3), true>(lds, ent, jj, mw, nm); else check_node<(D >= 3 ? D : 3), false>(lds, ent, jj, mw, nm); } break;
+#define DVBS2_DEG_SWITCH switch (deg) { \
+        DVBS2_DEG_CASE(3) DVBS2_DEG_CASE(4) DVBS2_DEG_CASE(5) DVBS2_DEG_CASE(6) DVBS2_DEG_CASE(7) DVBS2_DEG_CASE(8) \
+        DVBS2_DEG_CASE(9) DVBS2_DEG_CASE(10) DVBS2_DEG_CASE(11) DVBS2_DEG_CASE(12) DVBS2_DEG_CASE(13) DVBS2_DEG_CASE(14) \
+        DVBS2_DEG_CASE(15) DVBS2_DEG_CASE(16) DVBS2_DEG_CASE(17) DVBS2_DEG_CASE(18) DVBS2_DEG_CASE(19) DVBS2_DEG_CASE(20) \
+        DVBS2_DEG_CASE(21) DVBS2_DEG_CASE(22) DVBS2_DEG_CASE(23) DVBS2_DEG_CASE(24) DVBS2_DEG_CASE(25) DVBS2_DEG_CASE(26) \
+        DVBS2_DEG_CASE(27) DVBS2_DEG_CASE(28) DVBS2_DEG_CASE(29) DVBS2_DEG_CASE(30) DVBS2_DEG_CASE(31) DVBS2_DEG_CASE(32) \
+        default: break; }
+
+template <int DMAX, bool TIMING>
+__global__ __launch_bounds__(kThreads) void ldpc_layered_kernel(
+    const uint32_t* __restrict__ recs, const int8_t* __restrict__ llr_in, uint8_t* __restrict__ state,
+    uint32_t* __restrict__ msgs, int* __restrict__ iters, int* __restrict__ good, const int* __restrict__ target,
+    int n_frames, int N, int K, int q, int cap, int stop_on_good, unsigned long long* __restrict__ tdbg)
+{
+    unsigned long long tm_bar = 0, tm_body = 0, tm_conf = 0, tm_synd = 0, tm_sweep = 0, tm_load = 0;
+#define TSTAMP(x) do { if (TIMING) { x = __builtin_readcyclecounter(); } } while (0)
+    unsigned long long tA = 0, tB = 0, tC = 0, tS0 = 0, tS1 = 0;
+    TSTAMP(tA);
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_all[];
+    constexpr int RS = rec_stride(DMAX);
+    constexpr int MW = DMAX / 4; // message dwords per check (fixed per kernel variant)
+    const int half = threadIdx.x >= kHalf ? 1 : 0; // wave-uniform
+    const int tid = threadIdx.x - half * kHalf;
+    uint8_t* lds = lds_all + half * half_lds_bytes(N);
+    uint32_t* sv = reinterpret_cast<uint32_t*>(lds + N); // N % 8 == 0
+    volatile int* flags = reinterpret_cast<volatile int*>(sv + (N / kM) * kSvWords); // [0] bad-or, [1] finished
+    volatile int* other_flags = reinterpret_cast<volatile int*>(
+        lds_all + (1 - half) * half_lds_bytes(N) + N + (size_t)(N / kM) * kSvWords * 4);
+    const int f = 2 * blockIdx.x + half;
+    const bool have_frame = f < n_frames;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int NG = N / kM;
+    const bool active = tid < kM;
+
+    int it = 0, tgt = 0;
+    bool finished = !have_frame; // this half has nothing (more) to do; it still takes part in every barrier
+    if (have_frame) {
+        tgt = target ? target[f] : cap;
+        if (llr_in) {
+            const uint2* src = reinterpret_cast<const uint2*>(llr_in + (size_t)f * N);
+            for (int c = tid; c < N / 8; c += kHalf) {
+                uint2 v = src[c];
+                v.x ^= 0x80808080u; v.y ^= 0x80808080u;
+                const int n = 8 * c;
+                if (n < K) *reinterpret_cast<uint2*>(lds + n) = v; // K % 8 == 0
+                else {
+                    // pty[360*i + j] = parity[q*j + i] (layered_decoder.hh:150-152)
+                    int r = n - K;
+                    int jq = r / q, iq = r - jq * q;
+#pragma unroll
+                    for (int b = 0; b < 8; b++) {
+                        lds[K + kM * iq + jq] = (uint8_t)((b < 4 ? v.x >> (8 * b) : v.y >> (8 * (b - 4))) & 0xffu);
+                        if (++iq == q) { iq = 0; ++jq; }
+                    }
+                }
+            }
+        } else {
+            it = iters[f];
+            if (it >= tgt) finished = true; // nothing to do for this frame in this pass
+            else {
+                const uint2* src = reinterpret_cast<const uint2*>(state + (size_t)f * N);
+                for (int c = tid; c < N / 8; c += kHalf) *reinterpret_cast<uint2*>(lds + 8 * c) = src[c];
+            }
+        }
+    }
+    const bool untouched = finished; // never loaded: must not write state/iters/good back
+    if (tid == 0) { flags[0] = 0; flags[1] = finished ? 1 : 0; }
+    __syncthreads();
+    TSTAMP(tB); tm_load = tB - tA;
+
+    uint32_t* msg_base = msgs + (size_t)(have_frame ? f : 0) * q * MW * kMsgStride;
+    bool is_good = false;
 
     for (;;) {
-        if (a.stop_on_good || it >= tgt) {
-            // ---- syndrome test: layered_decoder.hh:32-49, algorithms.hh:195-202 (cnv <= 0 is bad:
-            // a zero LLR on a check or an odd number of negative LLRs) ----
-            int bad = 0;
-            if (j < kM) {
-                for (int i = 0; i < q; i++) {
-                    const uint32_t eoff = a.layers[2 * i];
-                    const int deg = (int)(a.layers[2 * i + 1] & 0xffff) + 2;
-                    uint32_t x = 0, z = 0;
-                    for (int k = 0; k < deg; k++) {
-                        const uint32_t e = a.entries[eoff + k];
-                        int t = j + (int)(e >> 16);
-                        t = t >= kM ? t - kM : t;
-                        uint32_t v = lds[(e & 0xffff) + t];
-                        const bool valid = (i | j | (k ^ (deg - 1))) != 0; // check (0,0) has no previous parity
-                        v = valid ? v : 0x81u; // +1: neutral
-                        x ^= v;
-                        z |= (v == 0x80u);
-                    }
-                    // offset binary: sign bit is inverted; deg links (deg-1 real + neutral for (0,0))
-                    const uint32_t neg_parity = ((x >> 7) ^ (uint32_t)deg) & 1u;
-                    bad |= (int)(neg_parity | z);
-                }
+        TSTAMP(tS0);
+        // ---- syndrome test (layered_decoder.hh:32-49, algorithms.hh:195-202): bad if any check has a zero
+        // LLR or an odd number of negative LLRs. Barriers are taken by every thread; work only by halves that need it.
+        const bool need_synd = !finished && (stop_on_good || it >= tgt);
+        if (need_synd) {
+            // Step 1: 360-bit sign vector per group via wave ballots.
+            unsigned long long zero_any = 0;
+            for (int g = 0; g < NG; g++) {
+                const uint32_t v = active ? lds[kM * g + tid] : 0xffu;
+                const unsigned long long neg = __ballot(v < 0x80u);
+                zero_any |= __ballot(v == 0x80u);
+                if (lane == 0) { sv[g * kSvWords + 2 * wave] = (uint32_t)neg; sv[g * kSvWords + 2 * wave + 1] = (uint32_t)(neg >> 32); }
             }
-            good = !__syncthreads_or(bad);
+            if (zero_any != 0 && lane == 0) flags[0] = 1;
         }
-        if (it >= tgt) break;
-        if (a.stop_on_good && good) break;
+        __syncthreads();
+        if (need_synd && tid < NG) { // wrap extension: bits 360+u = bit u
+            uint32_t* p = sv + tid * kSvWords;
+            const uint32_t w0 = p[0], w1 = p[1];
+            p[11] = (p[11] & 0xffu) | (w0 << 8);
+            p[12] = (w0 >> 24) | (w1 << 8);
+        }
+        __syncthreads();
+        if (need_synd) {
+            // Step 2: parity word (layer i, lanes 32w..32w+31) = xor over entries of the rotated sign vectors
+            int bad = 0;
+            for (int item = tid; item < q * 12; item += kHalf) {
+                const int i = item / 12, w = item - 12 * i;
+                const uint32_t* rec = recs + (size_t)i * RS;
+                const int deg = (int)(rec[0] & 0x7fffu) + 2;
+                uint32_t acc = 0;
+                for (int k = 0; k < deg; k++) {
+                    const int S0 = (int)rec[4 + 2 * k], thr = (int)rec[5 + 2 * k];
+                    const int rot = kM - thr;          // S0 = 360*g + rot
+                    const int g360 = S0 - rot;
+                    const int t0 = wrap360(32 * w + rot);
+                    const uint32_t* p = sv + (g360 / kM) * kSvWords + (t0 >> 5);
+                    uint32_t x = __funnelshift_r(p[0], p[1], t0 & 31);
+                    if (i == 0 && k == deg - 1 && w == 0) x &= ~1u; // check (0,0): no previous parity
+                    acc ^= x;
+                }
+                if (w == 11) acc &= 0xffu;
+                bad |= acc != 0;
+            }
+            if (__ballot(bad) != 0 && lane == 0) flags[0] = 1;
+        }
+        __syncthreads();
+        if (need_synd) is_good = flags[0] == 0;
+        if (!finished && (it >= tgt || (stop_on_good && is_good))) finished = true;
+        __syncthreads(); // everyone has read flags[0]
+        if (tid == 0) { flags[0] = 0; flags[1] = finished ? 1 : 0; }
+        __syncthreads();
+        TSTAMP(tS1); tm_synd += tS1 - tS0;
+        if (finished && other_flags[1]) break; // uniform over the workgroup
 
         // ---- one update sweep: layered_decoder.hh:50-79 ----
-        const bool first = (it == 0); // bnl == 0 (layered_decoder.hh:27-31)
+        const bool work = !finished && active;
+        uint32_t pre[MW]; // messages of the next layer for check tid, loaded one layer ahead
+        if (work) {
+#pragma unroll
+            for (int w = 0; w < MW; w++) pre[w] = msg_base[w * kMsgStride + tid];
+        }
         for (int i = 0; i < q; i++) {
-            const uint32_t eoff = a.layers[2 * i];
-            const uint32_t cb = a.layers[2 * i + 1];
-            const int deg = (int)(cb & 0xffff) + 2;
-            const int block = (int)(cb >> 16);
-            const int nw = (deg + 3) >> 2;
-            uint32_t* mp = msg_base + (size_t)i * a.wpc * kThreads;
-            for (int start = 0; start < kM; start += block) {
-                const int jj = start + tid; // block >= 360 -> single pass with jj = tid
-                if (tid < block && jj < kM) {
-                    uint32_t mw[DMAX / 4];
+            const uint32_t* rec = recs + (size_t)i * RS;
+            const uint32_t hdr = rec[0];
+            uint32_t ent[2 * DMAX];
 #pragma unroll
-                    for (int w = 0; w < DMAX / 4; w++) mw[w] = (w < nw && !first) ? mp[w * kThreads + jj] : 0x80808080u;
-                    int d[DMAX], mg[DMAX], ad[DMAX];
-                    int min0 = 127, min1 = 127, signs = 0;
+            for (int k = 0; k < 2 * DMAX; k++) ent[k] = rec[4 + k];
+            const int deg = (int)(hdr & 0x7fffu) + 2;
+            const int block = (int)(hdr >> 16);
+            const bool layer0 = (i == 0);
+            uint32_t* mp = msg_base + (size_t)i * MW * kMsgStride;
+            TSTAMP(tA);
+            if (hdr & 0x8000u) __syncthreads();
+            TSTAMP(tB); tm_bar += tB - tA;
+            if (block >= kM) {
+                // regular layer: all 360 checks at once
+                if (work) {
+                    const int jj = tid;
+                    uint32_t mw[MW], nm[MW];
 #pragma unroll
-                    for (int k = 0; k < DMAX; k++) {
-                        if (k < deg) {
-                            const uint32_t e = a.entries[eoff + k];
-                            int t = jj + (int)(e >> 16);
-                            t = t >= kM ? t - kM : t;
-                            ad[k] = (int)(e & 0xffff) + t;
-                            const int Lb = lds[ad[k]];
-                            const int mb = (int)((mw[k >> 2] >> (8 * (k & 3))) & 0xffu);
-                            const bool valid = (i | jj | (k ^ (deg - 1))) != 0;
-                            // R1: inp = sat8(L - m); R2: mag = usat(qabs(inp) - 1) = med3(|L - m| - 1, 0, 126)
-                            int dd = Lb - mb;
-                            int ab = dd < 0 ? -dd : dd;
-                            int mag = min(max(ab - 1, 0), 126);
-                            dd = valid ? dd : 0;
-                            mag = valid ? mag : 127;
-                            d[k] = dd; mg[k] = mag;
-                            // R3: two smallest magnitudes; R4: xor of signs
-                            min1 = min(min1, max(min0, mag));
-                            min0 = min(min0, mag);
-                            signs ^= dd;
+                    for (int w = 0; w < MW; w++) mw[w] = pre[w];
+                    if (i + 1 < q) {
+#pragma unroll
+                        for (int w = 0; w < MW; w++) pre[w] = mp[(MW + w) * kMsgStride + tid];
+                    }
+                    DVBS2_DEG_SWITCH
+#pragma unroll
+                    for (int w = 0; w < MW; w++) mp[w * kMsgStride + jj] = nm[w];
+                }
+                TSTAMP(tC); tm_body += tC - tB;
+            } else {
+                // sequential-order hazard inside the layer (ldpc_schedule.h): the first wave of the half walks the
+                // 360 checks alone in ascending chunks of min(B_i, 64); LDS operations of one wave execute in
+                // order, so the chunks need no barrier between them.
+                if (!finished && wave == 0) {
+                    const int chunk = block < 64 ? block : 64;
+                    uint32_t nx[MW];
+                    if (lane < chunk) {
+#pragma unroll
+                        for (int w = 0; w < MW; w++) nx[w] = mp[w * kMsgStride + lane];
+                    }
+                    for (int start = 0; start < kM; start += chunk) {
+                        const int jj = start + lane;
+                        if (lane < chunk && jj < kM) {
+                            uint32_t mw[MW], nm[MW];
+#pragma unroll
+                            for (int w = 0; w < MW; w++) mw[w] = nx[w];
+                            if (jj + chunk < kM) {
+#pragma unroll
+                                for (int w = 0; w < MW; w++) nx[w] = mp[w * kMsgStride + jj + chunk];
+                            }
+                            DVBS2_DEG_SWITCH
+#pragma unroll
+                            for (int w = 0; w < MW; w++) mp[w * kMsgStride + jj] = nm[w];
                         }
                     }
-                    uint32_t nm[DMAX / 4];
-#pragma unroll
-                    for (int w = 0; w < DMAX / 4; w++) nm[w] = 0;
-#pragma unroll
-                    for (int k = 0; k < DMAX; k++) {
-                        if (k < deg) {
-                            const bool valid = (i | jj | (k ^ (deg - 1))) != 0;
-                            // R5: out = vsign(other, (signs ^ x) | 127)
-                            const int other = (mg[k] == min0) ? min1 : min0;
-                            const int out = ((signs ^ d[k]) < 0) ? -other : other;
-                            // R6: LLR = sat8(inp + out), unclamped out
-                            const int inp = min(max(d[k], -128), 127);
-                            const int nl = min(max(inp + out, -128), 127) + 128;
-                            if (valid) lds[ad[k]] = (uint8_t)nl;
-                            // R7: bnl = clamp(out, -32, 31)
-                            const int nmsg = min(max(out, -32), 31) + 128;
-                            nm[k >> 2] |= (uint32_t)nmsg << (8 * (k & 3));
-                        }
-                    }
-#pragma unroll
-                    for (int w = 0; w < DMAX / 4; w++)
-                        if (w < nw) mp[w * kThreads + jj] = nm[w];
                 }
                 __syncthreads();
+                if (work && i + 1 < q) {
+#pragma unroll
+                    for (int w = 0; w < MW; w++) pre[w] = mp[(MW + w) * kMsgStride + tid];
+                }
+                TSTAMP(tC); tm_conf += tC - tB;
             }
         }
-        it++;
+        TSTAMP(tA);
+        __syncthreads();
+        TSTAMP(tB); tm_bar += tB - tA; tm_sweep += tB - tS1;
+        if (!finished) it++;
+    }
+    if (TIMING && tdbg && lane == 0 && have_frame) {
+        unsigned long long* o = tdbg + ((size_t)f * 6 + wave) * 8;
+        o[0] = tm_load; o[1] = tm_synd; o[2] = tm_sweep; o[3] = tm_bar; o[4] = tm_body; o[5] = tm_conf; o[6] = (unsigned long long)it; o[7] = 0;
     }
 
-    if (tid == 0) { a.iters[f] = it; a.good[f] = good ? 1 : 0; }
-    uint8_t* dst = a.state + (size_t)f * N;
-    for (int n = tid; n < N; n += kThreads) dst[n] = lds[n];
+    if (have_frame && !untouched) {
+        if (tid == 0) { iters[f] = it; good[f] = is_good ? 1 : 0; }
+        uint2* dst = reinterpret_cast<uint2*>(state + (size_t)f * N);
+        for (int c = tid; c < N / 8; c += kHalf) dst[c] = *reinterpret_cast<const uint2*>(lds + 8 * c);
+    }
 }
 
 // Per-group stopping rule of one reference SIMD batch: while (bad(any lane) && --trials >= 0) update(all lanes)
@@ -226,23 +370,28 @@ LdpcDecoderHip::LdpcDecoderHip(const LdpcTableDesc* table, int out_bits_message,
     if (!compile_ldpc_schedule(table, &sched_)) { err_ = "unknown or inconsistent LDPC table"; return; }
     if (G_ < 1 || max_frames_ < 1) { err_ = "bad group_size/max_frames"; return; }
     if (out_bits_message_ <= 0 || out_bits_message_ > sched_.N || out_bits_message_ % 8) { err_ = "bad message length"; return; }
-    const int degmax = sched_.cnt_max + 2;
-    dmax_ = degmax <= 8 ? 8 : degmax <= 16 ? 16 : 32;
+    int degmax = 0, degmin = 1000;
+    for (const LdpcLayer& L : sched_.layers) { degmax = std::max(degmax, L.cnt + 2); degmin = std::min(degmin, L.cnt + 2); }
     if (degmax > 32) { err_ = "check degree > 32 unsupported"; return; }
-    words_per_check_ = (degmax + 3) / 4;
+    dmax_ = std::max(8, (degmax + 3) / 4 * 4);
+    if (degmin < 3 || degmin <= dmax_ - 8) { err_ = "check degree spread unsupported by the kernel variants"; return; }
+    words_per_check_ = dmax_ / 4;
     HIP_OK(hipSetDevice(device_));
-    std::vector<uint32_t> hl(2 * sched_.q), he(sched_.entries.size());
+    const int RS = rec_stride(dmax_);
+    std::vector<uint32_t> hr((size_t)sched_.q * RS, 0);
     for (int i = 0; i < sched_.q; i++) {
-        hl[2 * i] = sched_.layers[i].entry_off;
-        hl[2 * i + 1] = sched_.layers[i].cnt | ((uint32_t)sched_.layers[i].block << 16);
+        const LdpcLayer& L = sched_.layers[i];
+        hr[(size_t)i * RS] = L.cnt | ((uint32_t)L.sync_before << 15) | ((uint32_t)L.block << 16);
+        for (int k = 0; k < L.cnt + 2; k++) {
+            const LdpcEntry& e = sched_.entries[L.entry_off + k];
+            hr[(size_t)i * RS + 4 + 2 * k] = (uint32_t)e.base + e.rot;
+            hr[(size_t)i * RS + 5 + 2 * k] = 360u - e.rot;
+        }
     }
-    for (size_t i = 0; i < he.size(); i++) he[i] = sched_.entries[i].base | ((uint32_t)sched_.entries[i].rot << 16);
-    HIP_OK(hipMalloc(&d_layers_, hl.size() * 4));
-    HIP_OK(hipMalloc(&d_entries_, he.size() * 4));
-    HIP_OK(hipMemcpy(d_layers_, hl.data(), hl.size() * 4, hipMemcpyHostToDevice));
-    HIP_OK(hipMemcpy(d_entries_, he.data(), he.size() * 4, hipMemcpyHostToDevice));
+    HIP_OK(hipMalloc(&d_recs_, hr.size() * 4));
+    HIP_OK(hipMemcpy(d_recs_, hr.data(), hr.size() * 4, hipMemcpyHostToDevice));
     HIP_OK(hipMalloc(&d_state_, (size_t)max_frames_ * sched_.N));
-    HIP_OK(hipMalloc(&d_msgs_, (size_t)max_frames_ * sched_.q * words_per_check_ * kThreads * 4));
+    HIP_OK(hipMalloc(&d_msgs_, (size_t)max_frames_ * sched_.q * words_per_check_ * kMsgStride * 4));
     HIP_OK(hipMalloc(&d_iters_, (size_t)max_frames_ * 4));
     HIP_OK(hipMalloc(&d_good_, (size_t)max_frames_ * 4));
     HIP_OK(hipMalloc(&d_target_, (size_t)max_frames_ * 4));
@@ -250,15 +399,18 @@ LdpcDecoderHip::LdpcDecoderHip(const LdpcTableDesc* table, int out_bits_message,
     HIP_OK(hipHostMalloc(&h_flag_, 4));
     HIP_OK(hipEventCreate(&ev0_));
     HIP_OK(hipEventCreate(&ev1_));
-    const size_t lds_bytes = (size_t)sched_.N;
-    const void* fn = dmax_ == 8 ? (const void*)ldpc_layered_kernel<8> : dmax_ == 16 ? (const void*)ldpc_layered_kernel<16> : (const void*)ldpc_layered_kernel<32>;
-    HIP_OK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    if (getenv("DVBS2_TIMING")) { HIP_OK(hipMalloc(&d_tdbg_, (size_t)max_frames_ * 6 * 8 * 8)); HIP_OK(hipMemset(d_tdbg_, 0, (size_t)max_frames_ * 6 * 8 * 8)); }
+    lds_bytes_ = 2 * half_lds_bytes(sched_.N);
+#define DVBS2_ATTR(D) HIP_OK(hipFuncSetAttribute((const void*)ldpc_layered_kernel<D, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes_)); \
+    HIP_OK(hipFuncSetAttribute((const void*)ldpc_layered_kernel<D, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes_));
+    DVBS2_ATTR(8) DVBS2_ATTR(12) DVBS2_ATTR(16) DVBS2_ATTR(20) DVBS2_ATTR(24) DVBS2_ATTR(28) DVBS2_ATTR(32)
+#undef DVBS2_ATTR
 }
 
 LdpcDecoderHip::~LdpcDecoderHip()
 {
     (void)hipSetDevice(device_);
-    (void)hipFree(d_layers_); (void)hipFree(d_entries_); (void)hipFree(d_state_); (void)hipFree(d_msgs_);
+    (void)hipFree(d_recs_); (void)hipFree(d_state_); (void)hipFree(d_msgs_);
     (void)hipFree(d_iters_); (void)hipFree(d_good_); (void)hipFree(d_target_); (void)hipFree(d_flag_);
     if (h_flag_) (void)hipHostFree(h_flag_);
     if (ev0_) (void)hipEventDestroy(ev0_);
@@ -273,16 +425,15 @@ int LdpcDecoderHip::decode_device(const int8_t* d_llr_in, int n_frames, int max_
     if (n_frames == 0) return 0;
     if (max_trials < 0) { err_ = "max_trials < 0"; return -1; }
     HIP_RET(hipSetDevice(device_));
-    LdpcKernelArgs a;
-    a.layers = d_layers_; a.entries = d_entries_; a.llr_in = d_llr_in; a.state = d_state_; a.msgs = d_msgs_;
-    a.iters = d_iters_; a.good = d_good_; a.target = nullptr;
-    a.N = sched_.N; a.K = sched_.K; a.q = sched_.q; a.wpc = words_per_check_; a.cap = max_trials; a.stop_on_good = 1;
-    const size_t lds_bytes = (size_t)sched_.N;
-    auto launch = [&](const LdpcKernelArgs& ka) {
+    const size_t lds_bytes = lds_bytes_;
+    auto launch = [&](const int8_t* in, const int* target, int stop_on_good) {
         if (profiling_) (void)hipEventRecord(ev0_, stream);
-        if (dmax_ == 8) hipLaunchKernelGGL(ldpc_layered_kernel<8>, dim3(n_frames), dim3(kThreads), lds_bytes, stream, ka);
-        else if (dmax_ == 16) hipLaunchKernelGGL(ldpc_layered_kernel<16>, dim3(n_frames), dim3(kThreads), lds_bytes, stream, ka);
-        else hipLaunchKernelGGL(ldpc_layered_kernel<32>, dim3(n_frames), dim3(kThreads), lds_bytes, stream, ka);
+#define DVBS2_LAUNCH(D) case D: if (d_tdbg_) hipLaunchKernelGGL((ldpc_layered_kernel<D, true>), dim3((n_frames + 1) / 2), dim3(kThreads), lds_bytes, stream, \
+            d_recs_, in, d_state_, d_msgs_, d_iters_, d_good_, target, n_frames, sched_.N, sched_.K, sched_.q, max_trials, stop_on_good, d_tdbg_); \
+        else hipLaunchKernelGGL((ldpc_layered_kernel<D, false>), dim3((n_frames + 1) / 2), dim3(kThreads), lds_bytes, stream, \
+            d_recs_, in, d_state_, d_msgs_, d_iters_, d_good_, target, n_frames, sched_.N, sched_.K, sched_.q, max_trials, stop_on_good, d_tdbg_); break;
+        switch (dmax_) { DVBS2_LAUNCH(8) DVBS2_LAUNCH(12) DVBS2_LAUNCH(16) DVBS2_LAUNCH(20) DVBS2_LAUNCH(24) DVBS2_LAUNCH(28) DVBS2_LAUNCH(32) }
+#undef DVBS2_LAUNCH
         if (profiling_) {
             (void)hipEventRecord(ev1_, stream);
             (void)hipEventSynchronize(ev1_);
@@ -290,8 +441,19 @@ int LdpcDecoderHip::decode_device(const int8_t* d_llr_in, int n_frames, int max_
             prof_ms_ += ms; prof_launches_++;
         }
     };
-    launch(a);
+    // bnl = 0 before the first update (layered_decoder.hh:27-31,149): offset-binary zero bytes
+    HIP_RET(hipMemsetAsync(d_msgs_, 0x80, (size_t)n_frames * sched_.q * words_per_check_ * kMsgStride * 4, stream));
+    launch(d_llr_in, nullptr, 1);
     HIP_RET(hipGetLastError());
+    if (d_tdbg_) {
+        HIP_RET(hipStreamSynchronize(stream));
+        std::vector<unsigned long long> h((size_t)n_frames * 48);
+        HIP_RET(hipMemcpy(h.data(), d_tdbg_, h.size() * 8, hipMemcpyDeviceToHost));
+        double a[8] = {0};
+        for (size_t r = 0; r < (size_t)n_frames * 6; r++) for (int c = 0; c < 8; c++) a[c] += (double)h[r * 8 + c];
+        const double nr = (double)n_frames * 6;
+        fprintf(stderr, "[timing, 100MHz ticks per wave avg] load %.0f synd %.0f sweep %.0f (barrier %.0f body %.0f conflict-layers %.0f) iters %.1f\n", a[0]/nr, a[1]/nr, a[2]/nr, a[3]/nr, a[4]/nr, a[5]/nr, a[6]/nr);
+    }
     const int n_groups = (n_frames + G_ - 1) / G_;
     for (int round = 0;; round++) {
         HIP_RET(hipMemsetAsync(d_flag_, 0, 4, stream));
@@ -301,9 +463,7 @@ int LdpcDecoderHip::decode_device(const int8_t* d_llr_in, int n_frames, int max_
         HIP_RET(hipStreamSynchronize(stream));
         if (*h_flag_ == 0) break;
         if (round > 2 * max_trials + 2) { err_ = "group resolution did not converge"; return -1; }
-        LdpcKernelArgs r = a;
-        r.llr_in = nullptr; r.target = d_target_; r.stop_on_good = 0;
-        launch(r);
+        launch(nullptr, d_target_, 0);
         HIP_RET(hipGetLastError());
     }
     const int out_bytes = (out_mode ? out_bits_message_ : sched_.N) / 8;

@@ -1,6 +1,7 @@
 // ldpc_schedule.cpp -- see ldpc_schedule.h.
 #include "ldpc_schedule.h"
 #include <algorithm>
+#include <set>
 
 namespace dvbs2 {
 
@@ -29,6 +30,9 @@ bool compile_ldpc_schedule(const LdpcTableDesc* t, LdpcSchedule* out)
     }
     s.links_total = (int)(links + 2L * s.R - 1);
 
+    // Barrier elision: parity rows are always touched by the same thread (rot 0) except row q-1 in layer 0,
+    // so only the DATA groups (and that one row) can carry a cross-thread hazard between layers.
+    std::set<int> epoch;
     for (int i = 0; i < s.q; i++) {
         auto& v = per_layer[i];
         LdpcLayer L;
@@ -45,6 +49,17 @@ bool compile_ldpc_schedule(const LdpcTableDesc* t, LdpcSchedule* out)
                 }
         L.block = (uint16_t)block;
         if (block < 360) s.conflict_layers++;
+        std::set<int> mine;
+        for (const GS& e : v) mine.insert(e.g);
+        if (i == 0) mine.insert(t->nrows + s.q - 1);       // previous-parity row of layer 0 (rot 359)
+        if (i == s.q - 1) mine.insert(t->nrows + s.q - 1); // the same row, as own parity of the last layer
+        bool hit = (i == 0) || block < 360;
+        for (int g : mine) if (epoch.count(g)) hit = true;
+        L.sync_before = hit ? 1 : 0;
+        if (hit) epoch.clear();
+        epoch.insert(mine.begin(), mine.end());
+        if (block < 360) epoch.clear(); // a sub-blocked layer ends with a barrier of its own
+
         for (const GS& e : v)
             s.entries.push_back({ (uint16_t)(360 * e.g), (uint16_t)((360 - e.sh) % 360) });
         // own parity pty[360*i + j]
