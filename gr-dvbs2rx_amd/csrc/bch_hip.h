@@ -1,0 +1,48 @@
+// bch_hip.h -- device-side BCH decoder object behind the C ABI (include/dvbs2_fec_hip.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace dvbs2 {
+
+// Host-side GF(2^m) tables and the BCH code parameters, built the way the reference builds them:
+//   field elements by LFSR              reference lib/gf.cc:48-66
+//   g(x) = product of the DISTINCT minimal polynomials of alpha^1, alpha^3, .., alpha^(2t-1)   lib/bch.cc:37-62
+//   shortening s = 2^m - 1 - n, k = n - deg g                                                  lib/bch.cc:64-76
+//   quadratic LUT  lut[r*r ^ r] = r for r = 0 .. 2^m - 1 (later r overwrites)                  lib/bch.cc:107-112
+struct BchCode {
+    int m = 0, t = 0, n = 0, k = 0, s = 0, P = 0, gdeg = 0;
+    std::vector<uint16_t> antilog; // alpha^i, i in [0, P)
+    std::vector<uint16_t> log;     // log[x], x in [1, P]; log[0] unused
+    std::vector<uint16_t> quad;    // size P + 1
+    std::vector<uint8_t> gen;      // g(x) coefficients, gen[i] = coef of x^i
+    bool build(int m, uint32_t prim_poly, int t, int n, std::string* err);
+};
+
+class BchDecoderHip {
+public:
+    BchDecoderHip(int m, uint32_t prim_poly, int t, int n, int max_frames, int device);
+    ~BchDecoderHip();
+    bool ok() const { return err_.empty(); }
+    const std::string& error() const { return err_; }
+    const BchCode& code() const { return code_; }
+    int max_frames() const { return max_frames_; }
+    // DEVICE pointers. d_cw: n_frames * n/8 bytes (first bit = x^(n-1), reference lib/bch.cc:436-449);
+    // d_msg: n_frames * k/8 bytes; d_corr: per frame  >= 0 corrected bits, -1 failure, -2 the reference would
+    // have thrown (lib/gf.h:110 via lib/bch.cc:359-367, or lib/bch.cc:443-444).
+    int decode_device(const uint8_t* d_cw, int n_frames, uint8_t* d_msg, int32_t* d_corr, hipStream_t stream);
+
+private:
+    BchCode code_;
+    int max_frames_, device_;
+    uint16_t* d_antilog_ = nullptr;
+    uint16_t* d_log_ = nullptr;
+    uint16_t* d_quad_ = nullptr;
+    int n_cus_ = 0;
+    size_t lds_bytes_ = 0;
+    std::string err_;
+};
+
+} // namespace dvbs2

@@ -1,0 +1,297 @@
+// bch_hip.hip -- GF(2^m) BCH syndrome / Berlekamp / Chien decoder for the DVB-S2/S2X outer code on gfx950.
+//
+// Bit-exact contract: bch_codec<uint32_t, bitset256_t>::decode(u8_cptr_t, u8_ptr_t) of the reference
+// (lib/bch.cc:468-487) including its behaviour beyond t errors (partial corrections, return -1) and the
+// two places where it throws (reported as -2 instead of unwinding through the C ABI).
+//
+// Mapping: persistent workgroups of 1024 threads, one per CU, each keeping the antilog table of the field
+// (2^m - 1 entries, 128 KB for GF(2^16)) in LDS for its whole life; frames are dealt round-robin.
+//   syndromes   S_i = r(alpha^i), i odd: every thread owns a stride of codeword bytes and adds
+//               alpha^(i*e mod P) for each set bit of exponent e (== remainder-then-evaluate of the
+//               reference, lib/bch.cc:176-189,217-222: rem(alpha^i) = r(alpha^i), and rem == 0 <=> all S_i == 0);
+//               S_2i = S_i^2.
+//   sigma(x)    simplified Berlekamp table (lib/bch.cc:225-304), one thread, log/antilog arithmetic.
+//   roots       degree 1 and 2 closed forms (lib/bch.cc:316-367); otherwise a Chien search over the
+//               exponents [s+1, n+s] (lib/bch.cc:376-384, lib/gf.cc:376-401), all threads, LDS gathers.
+//   correction  message bits only, network bit order (lib/bch.cc:429-452).
+#include "bch_hip.h"
+#include <algorithm>
+#include <cstring>
+
+namespace dvbs2 {
+
+bool BchCode::build(int m_, uint32_t prim_poly, int t_, int n_, std::string* err)
+{
+    m = m_; t = t_;
+    if (m < 3 || m > 16 || t < 1 || t > 12) { *err = "unsupported GF(2^m) dimension or t"; return false; }
+    P = (1 << m) - 1;
+    antilog.assign(P, 0); log.assign(P + 1, 0);
+    const uint32_t low = prim_poly ^ (1u << m);
+    uint32_t x = 1;
+    for (int i = 0; i < P; i++) {
+        antilog[i] = (uint16_t)x; log[x] = (uint16_t)i;
+        x = ((x << 1) & (uint32_t)P) ^ ((x >> (m - 1)) * low);
+    }
+    auto gmul = [&](uint32_t a, uint32_t b) -> uint32_t { return (!a || !b) ? 0u : antilog[(log[a] + log[b]) % P]; };
+    // generator polynomial
+    std::vector<uint8_t> seen(P + 1, 0);
+    gen.assign(1, 1);
+    for (int i = 0; i < t; i++) {
+        uint32_t e = (uint32_t)((2 * i + 1) % P);
+        if (seen[antilog[e]]) continue;
+        std::vector<uint32_t> conj;
+        uint32_t ee = e;
+        for (int j = 0; j < m; j++) {
+            uint32_t el = antilog[ee];
+            if (std::find(conj.begin(), conj.end(), el) != conj.end()) break;
+            conj.push_back(el); seen[el] = 1;
+            ee = (uint32_t)(((uint64_t)ee * 2) % P);
+        }
+        std::vector<uint32_t> mp(1, 1);
+        for (uint32_t c : conj) {
+            std::vector<uint32_t> nx(mp.size() + 1, 0);
+            for (size_t d = 0; d < mp.size(); d++) { nx[d + 1] ^= mp[d]; nx[d] ^= gmul(mp[d], c); }
+            mp.swap(nx);
+        }
+        std::vector<uint8_t> ng(gen.size() + mp.size() - 1, 0);
+        for (size_t a = 0; a < gen.size(); a++) if (gen[a]) for (size_t d = 0; d < mp.size(); d++) {
+            if (mp[d] > 1) { *err = "minimal polynomial is not binary"; return false; }
+            ng[a + d] ^= (uint8_t)mp[d];
+        }
+        gen.swap(ng);
+    }
+    gdeg = (int)gen.size() - 1;
+    n = n_ ? n_ : P;
+    if (n > P) { *err = "Codeword length n exceeds the maximum of (2^m - 1)"; return false; }
+    if (n <= gdeg) { *err = "Codeword length n must be greater than the generator polynomial's degree"; return false; }
+    s = P - n; k = n - gdeg;
+    quad.assign(P + 1, 0);
+    for (uint32_t r = 0; r <= (uint32_t)P; r++) quad[gmul(r, r) ^ r] = (uint16_t)r;
+    return true;
+}
+
+constexpr int kBchThreads = 1024;
+constexpr int kMaxT = 12;
+
+struct BchArgs {
+    const uint16_t* antilog; const uint16_t* log; const uint16_t* quad;
+    const uint8_t* cw; uint8_t* msg; int32_t* corr;
+    int n_frames, m, P, t, n, k, s;
+};
+
+__device__ __forceinline__ uint32_t modP(uint32_t x, int m, uint32_t P)
+{
+    x = (x & P) + (x >> m);
+    x = (x & P) + (x >> m);
+    return x >= P ? x - P : x;
+}
+
+__global__ __launch_bounds__(kBchThreads) void bch_decode_kernel(BchArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int tid = threadIdx.x;
+    const uint32_t P = (uint32_t)a.P;
+    const int m = a.m, t = a.t, n = a.n, k = a.k;
+    const int nb = n / 8, kb = k / 8;
+    uint16_t* al = reinterpret_cast<uint16_t*>(smem);                  // antilog, P entries
+    uint32_t* w = reinterpret_cast<uint32_t*>(smem + (((size_t)P * 2 + 15) & ~(size_t)15));
+    uint32_t* S = w;            // [2t] syndromes S_1..S_2t
+    uint32_t* lsig = w + 32;    // [t+1] log of sigma coefficients, 0xffffffff for zero
+    uint32_t* roots = w + 64;   // [<=16] root exponents found by the Chien search
+    int* ctl = reinterpret_cast<int*>(w + 96); // [0] degree, [1] nroots, [2] mode, [3] status
+    uint32_t (*sg)[kMaxT + 3] = reinterpret_cast<uint32_t (*)[kMaxT + 3]>(w + 128); // Berlekamp table rows
+    int* dg = reinterpret_cast<int*>(w + 368);
+    uint32_t* d = w + 384;
+    int* two_mu = reinterpret_cast<int*>(w + 400);
+    uint8_t* cwl = reinterpret_cast<uint8_t*>(w + 512);                // codeword bytes
+
+    for (uint32_t i = tid; i < P; i += kBchThreads) al[i] = a.antilog[i];
+
+    for (int f = blockIdx.x; f < a.n_frames; f += gridDim.x) {
+        __syncthreads();
+        const uint8_t* cw = a.cw + (size_t)f * nb;
+        uint8_t* out = a.msg + (size_t)f * kb;
+        for (int b = tid; b < nb; b += kBchThreads) { const uint8_t v = cw[b]; cwl[b] = v; if (b < kb) out[b] = v; } // lib/bch.cc:471
+        if (tid < 2 * kMaxT) S[tid] = 0;
+        if (tid == 0) { ctl[0] = 0; ctl[1] = 0; ctl[2] = 0; ctl[3] = 0; }
+        __syncthreads();
+
+        // ---- odd syndromes ----
+        uint32_t acc[kMaxT];
+#pragma unroll
+        for (int u = 0; u < kMaxT; u++) acc[u] = 0;
+        for (int b = tid; b < nb; b += kBchThreads) {
+            uint32_t v = cwl[b];
+            while (v) {
+                const int hb = 31 - __clz((int)v); // bit value 1<<hb of the byte = stream position 8b + 7 - hb
+                v &= ~(1u << hb);
+                const uint32_t e = (uint32_t)(n - 1 - (8 * b + 7 - hb));
+#pragma unroll
+                for (int u = 0; u < kMaxT; u++)
+                    if (u < t) acc[u] ^= al[modP((uint32_t)(2 * u + 1) * e, m, P)];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kMaxT; u++) {
+            if (u < t) {
+                uint32_t v = acc[u];
+                for (int off = 32; off; off >>= 1) v ^= __shfl_xor((int)v, off);
+                if ((tid & 63) == 0 && v) atomicXor(&S[2 * u], v); // S_(2u+1) lives at S[2u]
+            }
+        }
+        __syncthreads();
+
+        if (tid == 0) {
+            auto lg = [&](uint32_t x) -> uint32_t { return a.log[x]; };
+            auto mul = [&](uint32_t x, uint32_t y) -> uint32_t { return (!x || !y) ? 0u : (uint32_t)al[modP(lg(x) + lg(y), m, P)]; };
+            auto inv = [&](uint32_t x) -> uint32_t { return (uint32_t)al[modP(P - lg(x), m, P)]; }; // x != 0
+            bool any = false;
+            for (int u = 0; u < t; u++) any |= S[2 * u] != 0;
+            if (!any) { ctl[2] = 0; ctl[3] = 0; } // error-free fast path (lib/bch.cc:181-182,484-486)
+            else {
+                // even syndromes: S_2i = S_i^2
+                for (int i = 2; i <= 2 * t; i += 2) S[i - 1] = mul(S[i / 2 - 1], S[i / 2 - 1]);
+                // ---- simplified Berlekamp (lib/bch.cc:225-304) ----
+                for (int r = 0; r < t + 3; r++) for (int c = 0; c < t + 3; c++) sg[r][c] = 0;
+                two_mu[0] = -1;
+                for (int i = 0; i < t + 1; i++) two_mu[i + 1] = 2 * i;
+                sg[0][0] = 1; dg[0] = 0; sg[1][0] = 1; dg[1] = 0;
+                sg[2][0] = 1; sg[2][1] = S[0]; dg[2] = S[0] ? 1 : 0;
+                d[0] = 1; d[1] = S[0];
+                int row = 2;
+                while (row <= t) {
+                    const int tm = two_mu[row];
+                    uint32_t dr = S[tm];
+                    for (int j = 1; j <= dg[row]; j++) if (sg[row][j]) dr ^= mul(sg[row][j], S[tm - j]);
+                    d[row] = dr;
+                    if (dr == 0) { for (int c = 0; c < t + 3; c++) sg[row + 1][c] = sg[row][c]; dg[row + 1] = dg[row]; }
+                    else {
+                        int row_rho = 0, max_diff = -2;
+                        for (int j = row - 1; j >= 0; j--)
+                            if (d[j] != 0) { const int diff = two_mu[j] - dg[j]; if (diff > max_diff) { max_diff = diff; row_rho = j; } }
+                        const int shift = tm - two_mu[row_rho];
+                        const uint32_t coef = mul(dr, inv(d[row_rho]));
+                        for (int c = 0; c < t + 3; c++) sg[row + 1][c] = sg[row][c];
+                        int top = dg[row];
+                        for (int j = 0; j <= dg[row_rho]; j++)
+                            if (j + shift < t + 3) sg[row + 1][j + shift] ^= mul(coef, sg[row_rho][j]);
+                        if (dg[row_rho] + shift > top) top = dg[row_rho] + shift;
+                        if (top > t + 2) top = t + 2;
+                        while (top >= 0 && sg[row + 1][top] == 0) top--;
+                        dg[row + 1] = top;
+                    }
+                    row++;
+                }
+                const int deg = dg[row];
+                const uint32_t* sigma = sg[row];
+                ctl[0] = deg;
+                // ---- error-location numbers (lib/bch.cc:307-385) ----
+                int mode = 1, nnum = 0, status = 0; // mode 1: numbers ready in roots[] as bit indices; 2: Chien needed
+                uint32_t num[2] = { 0, 0 };
+                if (deg > t) { nnum = 0; }
+                else if (deg == 1) { num[0] = mul(sigma[1], inv(sigma[0])); nnum = 1; }
+                else if (deg == 2) {
+                    if (sigma[1] == 0 || sigma[0] == 0) nnum = 0;
+                    else {
+                        const uint32_t b_over_a = mul(sigma[1], inv(sigma[2]));
+                        const uint32_t rr = mul(mul(sigma[0], sigma[2]), inv(mul(sigma[1], sigma[1])));
+                        const uint32_t r = a.quad[rr];
+                        const uint32_t x0 = mul(r, b_over_a), x1 = mul(b_over_a, r ^ 1u);
+                        if (x0 == 0 || x1 == 0) status = -2; // galois_field::inverse(0) throws (lib/gf.h:110)
+                        else { num[0] = inv(x0); num[1] = inv(x1); nnum = 2; }
+                    }
+                } else {
+                    mode = 2;
+                    for (int j = 0; j <= deg; j++) lsig[j] = sigma[j] ? lg(sigma[j]) : 0xffffffffu;
+                }
+                if (mode == 1 && status == 0) {
+                    for (int i = 0; i < nnum; i++) roots[i] = lg(num[i]); // bit index = exponent of the number
+                    ctl[1] = nnum;
+                }
+                ctl[2] = mode; ctl[3] = status;
+                if (mode == 1 && status == -2) ctl[2] = 3; // nothing to apply
+            }
+        }
+        __syncthreads();
+        const int mode = ctl[2], deg = ctl[0];
+        if (mode == 0) { if (tid == 0) a.corr[f] = 0; continue; }
+        if (mode == 3) { if (tid == 0) a.corr[f] = -2; continue; }
+        if (mode == 2) {
+            // ---- Chien search over exponents [s+1, n+s]; a degree-deg polynomial has at most deg roots, so
+            // collecting all of them equals the reference's early-stopping scan ----
+            for (uint32_t i = (uint32_t)a.s + 1 + tid; i <= (uint32_t)(n + a.s); i += kBchThreads) {
+                uint32_t res = 0;
+                for (int j = 0; j <= deg; j++) {
+                    const uint32_t l = lsig[j];
+                    if (l != 0xffffffffu) res ^= al[modP(l + i * (uint32_t)j, m, P)];
+                }
+                if (res == 0) { const int idx = atomicAdd(&ctl[1], 1); if (idx < 16) roots[idx] = i; }
+            }
+            __syncthreads();
+        }
+        if (tid == 0) {
+            int nr = ctl[1] < 16 ? ctl[1] : 16;
+            if (mode == 2) {
+                // ascending exponent order, at most deg of them; number = alpha^(P - exp), bit index = P - exp (mod P)
+                for (int x = 1; x < nr; x++) { uint32_t v = roots[x]; int y = x - 1; while (y >= 0 && roots[y] > v) { roots[y + 1] = roots[y]; y--; } roots[y + 1] = v; }
+                if (nr > deg) nr = deg;
+                for (int x = 0; x < nr; x++) roots[x] = modP(P - modP(roots[x], m, P), m, P);
+            }
+            int status = (deg == nr) ? nr : -1;
+            for (int x = 0; x < nr; x++) { // lib/bch.cc:429-452
+                const uint32_t bit_idx = roots[x];
+                if (bit_idx >= (uint32_t)n) { status = -2; break; } // "Error location number out of range" (throws)
+                if (bit_idx < (uint32_t)(n - k)) continue;
+                const uint32_t net = (uint32_t)n - 1 - bit_idx;
+                out[net >> 3] ^= (uint8_t)(1u << (7 - (net & 7)));
+            }
+            a.corr[f] = status;
+        }
+    }
+}
+
+BchDecoderHip::BchDecoderHip(int m, uint32_t prim_poly, int t, int n, int max_frames, int device)
+    : max_frames_(max_frames), device_(device)
+{
+    if (!code_.build(m, prim_poly, t, n, &err_)) return;
+    if (code_.n % 8 || code_.k % 8) { err_ = "u8 array messages are only supported for n and k multiple of 8."; return; } // lib/bch.cc:19-24
+    if (max_frames_ < 1) { err_ = "bad max_frames"; return; }
+#define HIP_OK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { err_ = std::string(#x) + ": " + hipGetErrorString(e_); return; } } while (0)
+    HIP_OK(hipSetDevice(device_));
+    hipDeviceProp_t pr;
+    HIP_OK(hipGetDeviceProperties(&pr, device_));
+    n_cus_ = pr.multiProcessorCount;
+    HIP_OK(hipMalloc(&d_antilog_, code_.antilog.size() * 2));
+    HIP_OK(hipMalloc(&d_log_, code_.log.size() * 2));
+    HIP_OK(hipMalloc(&d_quad_, code_.quad.size() * 2));
+    HIP_OK(hipMemcpy(d_antilog_, code_.antilog.data(), code_.antilog.size() * 2, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(d_log_, code_.log.data(), code_.log.size() * 2, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(d_quad_, code_.quad.data(), code_.quad.size() * 2, hipMemcpyHostToDevice));
+    lds_bytes_ = (((size_t)code_.P * 2 + 15) & ~(size_t)15) + 512 * 4 + (size_t)((code_.n / 8 + 15) & ~15);
+    HIP_OK(hipFuncSetAttribute((const void*)bch_decode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes_));
+#undef HIP_OK
+}
+
+BchDecoderHip::~BchDecoderHip()
+{
+    (void)hipSetDevice(device_);
+    (void)hipFree(d_antilog_); (void)hipFree(d_log_); (void)hipFree(d_quad_);
+}
+
+int BchDecoderHip::decode_device(const uint8_t* d_cw, int n_frames, uint8_t* d_msg, int32_t* d_corr, hipStream_t stream)
+{
+    if (!ok()) return -1;
+    if (n_frames < 0 || n_frames > max_frames_) { err_ = "n_frames exceeds max_frames"; return -1; }
+    if (n_frames == 0) return 0;
+    if (hipSetDevice(device_) != hipSuccess) { err_ = "hipSetDevice failed"; return -1; }
+    BchArgs a;
+    a.antilog = d_antilog_; a.log = d_log_; a.quad = d_quad_; a.cw = d_cw; a.msg = d_msg; a.corr = d_corr;
+    a.n_frames = n_frames; a.m = code_.m; a.P = code_.P; a.t = code_.t; a.n = code_.n; a.k = code_.k; a.s = code_.s;
+    const int grid = std::min(n_frames, std::max(1, n_cus_));
+    hipLaunchKernelGGL(bch_decode_kernel, dim3(grid), dim3(kBchThreads), lds_bytes_, stream, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { err_ = std::string("bch kernel launch: ") + hipGetErrorString(e); return -1; }
+    return 0;
+}
+
+} // namespace dvbs2

@@ -7,12 +7,15 @@
 #include "fec_tables.h"
 #include "ldpc_hip.h"
 #include "ldpc_schedule.h"
+#include "bch_hip.h"
+#include "demap_hip.h"
 
 using namespace dvbs2;
 
 static thread_local std::string g_err;
 static int fail(int code, const std::string& msg) { g_err = msg; return code; }
 
+#define HCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(DVBS2_EDEVICE, std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
 #define API_TRY try {
 #define API_CATCH } catch (const std::exception& e) { return fail(DVBS2_EDEVICE, e.what()); } catch (...) { return fail(DVBS2_EDEVICE, "unknown exception"); }
 
@@ -163,7 +166,6 @@ int dvbs2_ldpc_decode(dvbs2_ldpc_t* h, const int8_t* llr_in, int n_frames, int m
     if (out_mode != DVBS2_OM_CODEWORD && out_mode != DVBS2_OM_MESSAGE) return fail(DVBS2_EINVAL, "bad out_mode");
     if (n_frames > h->dec->max_frames()) return fail(DVBS2_ESIZE, "n_frames exceeds max_frames");
     if (n_frames == 0) return DVBS2_OK;
-#define HCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(DVBS2_EDEVICE, std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
     HCHK(hipSetDevice(h->device));
     const size_t N = h->dec->N(), mf = h->dec->max_frames();
     const int G = h->dec->group_size();
@@ -192,6 +194,308 @@ int dvbs2_ldpc_profile(dvbs2_ldpc_t* h, int enable, double* total_ms, int* launc
     h->dec->set_profiling(enable != 0);
     if (enable) h->dec->reset_profile();
     return DVBS2_OK;
+}
+
+} // extern "C"
+
+/* ------------------------------------------------------------------ BCH */
+struct dvbs2_bch {
+    BchDecoderHip* dec = nullptr;
+    uint8_t* d_cw = nullptr; uint8_t* d_msg = nullptr; int32_t* d_corr = nullptr;
+    hipStream_t stream = nullptr;
+    int device = 0;
+};
+
+static int check_device(int device)
+{
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(DVBS2_EDEVICE, "no HIP device (this library has no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail(DVBS2_EINVAL, "device index out of range");
+    return DVBS2_OK;
+}
+
+static int bch_make(dvbs2_bch_t** h, int m, uint32_t prim_poly, int t, int n, int max_frames, int device)
+{
+    if (!h) return fail(DVBS2_EINVAL, "null handle pointer");
+    *h = nullptr;
+    if (int rc = check_device(device)) return rc;
+    dvbs2_bch* o = new (std::nothrow) dvbs2_bch();
+    if (!o) return fail(DVBS2_EDEVICE, "out of memory");
+    o->device = device;
+    o->dec = new (std::nothrow) BchDecoderHip(m, prim_poly, t, n, max_frames, device);
+    if (!o->dec || !o->dec->ok()) {
+        std::string msg = o->dec ? o->dec->error() : "out of memory";
+        delete o->dec; delete o;
+        return fail(msg.find("hip") != std::string::npos ? DVBS2_EDEVICE : DVBS2_EINVAL, msg);
+    }
+    *h = o;
+    return DVBS2_OK;
+}
+
+static void bch_field(int framesize, int* m, uint32_t* prim)
+{   // reference lib/bch_decoder_bb_impl.cc:58-63
+    if (framesize == DVBS2_FECFRAME_NORMAL) { *m = 16; *prim = 0x1002Du; }      // x^16 + x^5 + x^3 + x^2 + 1
+    else if (framesize == DVBS2_FECFRAME_SHORT) { *m = 14; *prim = 0x402Bu; }   // x^14 + x^5 + x^3 + x + 1
+    else { *m = 15; *prim = 0x802Du; }                                           // x^15 + x^5 + x^3 + x^2 + 1
+}
+
+extern "C" {
+
+int dvbs2_bch_create(dvbs2_bch_t** h, int standard, int framesize, int rate, int max_frames, int device)
+{
+    API_TRY
+    FecInfo fi;
+    if (!get_fec_info(standard, framesize, rate, &fi)) return fail(DVBS2_EINVAL, "unsupported (standard, framesize, rate)");
+    int m; uint32_t prim;
+    bch_field(framesize, &m, &prim);
+    int rc = bch_make(h, m, prim, (int)fi.bch_t, (int)fi.bch_n, max_frames, device);
+    if (rc == DVBS2_OK && (*h)->dec->code().k != (int)fi.bch_k) { dvbs2_bch_destroy(*h); *h = nullptr; return fail(DVBS2_EINVAL, "BCH k mismatch with the parameter table"); }
+    return rc;
+    API_CATCH
+}
+
+int dvbs2_bch_create_raw(dvbs2_bch_t** h, int m, uint32_t prim_poly, int t, int n, int max_frames, int device)
+{
+    API_TRY
+    return bch_make(h, m, prim_poly, t, n, max_frames, device);
+    API_CATCH
+}
+
+void dvbs2_bch_destroy(dvbs2_bch_t* h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    (void)hipFree(h->d_cw); (void)hipFree(h->d_msg); (void)hipFree(h->d_corr);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h->dec;
+    delete h;
+}
+
+int dvbs2_bch_params(const dvbs2_bch_t* h, int* n, int* k, int* t)
+{
+    if (!h) return fail(DVBS2_EINVAL, "null handle");
+    if (n) *n = h->dec->code().n; if (k) *k = h->dec->code().k; if (t) *t = h->dec->code().t;
+    return DVBS2_OK;
+}
+
+int dvbs2_bch_genpoly(const dvbs2_bch_t* h, uint8_t* gen, int max_coefs)
+{
+    if (!h) return fail(DVBS2_EINVAL, "null handle");
+    const auto& g = h->dec->code().gen;
+    if (gen) for (int i = 0; i < (int)g.size() && i < max_coefs; i++) gen[i] = g[i];
+    return h->dec->code().gdeg;
+}
+
+int dvbs2_bch_decode_device(dvbs2_bch_t* h, const uint8_t* d_cw, int n_frames, uint8_t* d_msg, int32_t* d_corr, void* stream)
+{
+    API_TRY
+    if (!h) return fail(DVBS2_EINVAL, "null handle");
+    if (n_frames < 0 || (n_frames && (!d_cw || !d_msg || !d_corr))) return fail(DVBS2_EINVAL, "bad argument");
+    if (n_frames > h->dec->max_frames()) return fail(DVBS2_ESIZE, "n_frames exceeds max_frames");
+    if (h->dec->decode_device(d_cw, n_frames, d_msg, d_corr, (hipStream_t)stream)) return fail(DVBS2_EDEVICE, h->dec->error());
+    return DVBS2_OK;
+    API_CATCH
+}
+
+int dvbs2_bch_decode(dvbs2_bch_t* h, const uint8_t* cw, int n_frames, uint8_t* msg, int32_t* corrections)
+{
+    API_TRY
+    if (!h) return fail(DVBS2_EINVAL, "null handle");
+    if (n_frames < 0 || (n_frames && (!cw || !msg || !corrections))) return fail(DVBS2_EINVAL, "bad argument");
+    if (n_frames > h->dec->max_frames()) return fail(DVBS2_ESIZE, "n_frames exceeds max_frames");
+    if (n_frames == 0) return DVBS2_OK;
+    HCHK(hipSetDevice(h->device));
+    const size_t nb = h->dec->code().n / 8, kb = h->dec->code().k / 8, mf = h->dec->max_frames();
+    if (!h->stream) HCHK(hipStreamCreate(&h->stream));
+    if (!h->d_cw) HCHK(hipMalloc(&h->d_cw, mf * nb));
+    if (!h->d_msg) HCHK(hipMalloc(&h->d_msg, mf * kb));
+    if (!h->d_corr) HCHK(hipMalloc(&h->d_corr, mf * 4));
+    HCHK(hipMemcpyAsync(h->d_cw, cw, (size_t)n_frames * nb, hipMemcpyHostToDevice, h->stream));
+    if (h->dec->decode_device(h->d_cw, n_frames, h->d_msg, h->d_corr, h->stream)) return fail(DVBS2_EDEVICE, h->dec->error());
+    HCHK(hipMemcpyAsync(msg, h->d_msg, (size_t)n_frames * kb, hipMemcpyDeviceToHost, h->stream));
+    HCHK(hipMemcpyAsync(corrections, h->d_corr, (size_t)n_frames * 4, hipMemcpyDeviceToHost, h->stream));
+    HCHK(hipStreamSynchronize(h->stream));
+    return DVBS2_OK;
+    API_CATCH
+}
+
+} // extern "C"
+
+/* ------------------------------------------------------------------ demapper */
+struct dvbs2_demap {
+    DemapperHip* dm = nullptr;
+    float* d_syms = nullptr; float* d_n0 = nullptr; int8_t* d_llr = nullptr; float* d_snr = nullptr;
+    hipStream_t stream = nullptr;
+    int device = 0;
+};
+
+extern "C" {
+
+int dvbs2_demap_create(dvbs2_demap_t** h, int framesize, int rate, int constellation, int max_frames, int device)
+{
+    API_TRY
+    if (!h) return fail(DVBS2_EINVAL, "null handle pointer");
+    *h = nullptr;
+    if (int rc = check_device(device)) return rc;
+    dvbs2_demap* o = new (std::nothrow) dvbs2_demap();
+    if (!o) return fail(DVBS2_EDEVICE, "out of memory");
+    o->device = device;
+    o->dm = new (std::nothrow) DemapperHip(framesize, rate, constellation, max_frames, device);
+    if (!o->dm || !o->dm->ok()) { std::string msg = o->dm ? o->dm->error() : "out of memory"; delete o->dm; delete o; return fail(DVBS2_EINVAL, msg); }
+    *h = o;
+    return DVBS2_OK;
+    API_CATCH
+}
+
+void dvbs2_demap_destroy(dvbs2_demap_t* h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    (void)hipFree(h->d_syms); (void)hipFree(h->d_n0); (void)hipFree(h->d_llr); (void)hipFree(h->d_snr);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h->dm;
+    delete h;
+}
+
+int dvbs2_demap_params(const dvbs2_demap_t* h, int* n_syms, int* n_llr, int* n_mod, int* column_order)
+{
+    if (!h) return fail(DVBS2_EINVAL, "null handle");
+    if (n_syms) *n_syms = h->dm->n_syms(); if (n_llr) *n_llr = h->dm->n_llr();
+    if (n_mod) *n_mod = h->dm->n_mod(); if (column_order) *column_order = h->dm->column_order();
+    return DVBS2_OK;
+}
+
+int dvbs2_demap_soft_device(dvbs2_demap_t* h, const float* d_syms, int n_frames, const float* d_n0, int n0_count, int8_t* d_llr_out, void* stream)
+{
+    API_TRY
+    if (!h) return fail(DVBS2_EINVAL, "null handle");
+    if (n_frames < 0 || (n_frames && (!d_syms || !d_n0 || !d_llr_out)) || (n0_count != 1 && n0_count != n_frames)) return fail(DVBS2_EINVAL, "bad argument");
+    if (n_frames > h->dm->max_frames()) return fail(DVBS2_ESIZE, "n_frames exceeds max_frames");
+    if (h->dm->soft_device(d_syms, n_frames, d_n0, n0_count, d_llr_out, (hipStream_t)stream)) return fail(DVBS2_EDEVICE, h->dm->error());
+    return DVBS2_OK;
+    API_CATCH
+}
+
+static int demap_stage(dvbs2_demap_t* h, const float* syms, int n_frames)
+{
+    HCHK(hipSetDevice(h->device));
+    const size_t mf = h->dm->max_frames(), ns = h->dm->n_syms();
+    if (!h->stream) HCHK(hipStreamCreate(&h->stream));
+    if (!h->d_syms) HCHK(hipMalloc(&h->d_syms, mf * ns * 8));
+    if (!h->d_n0) HCHK(hipMalloc(&h->d_n0, mf * 4));
+    if (!h->d_llr) HCHK(hipMalloc(&h->d_llr, mf * h->dm->n_llr()));
+    if (!h->d_snr) HCHK(hipMalloc(&h->d_snr, mf * 4));
+    HCHK(hipMemcpyAsync(h->d_syms, syms, (size_t)n_frames * ns * 8, hipMemcpyHostToDevice, h->stream));
+    return DVBS2_OK;
+}
+
+int dvbs2_demap_soft(dvbs2_demap_t* h, const float* syms, int n_frames, const float* n0, int n0_count, int8_t* llr_out)
+{
+    API_TRY
+    if (!h) return fail(DVBS2_EINVAL, "null handle");
+    if (n_frames < 0 || (n_frames && (!syms || !n0 || !llr_out)) || (n0_count != 1 && n0_count != n_frames)) return fail(DVBS2_EINVAL, "bad argument");
+    if (n_frames > h->dm->max_frames()) return fail(DVBS2_ESIZE, "n_frames exceeds max_frames");
+    if (n_frames == 0) return DVBS2_OK;
+    if (int rc = demap_stage(h, syms, n_frames)) return rc;
+    HCHK(hipMemcpyAsync(h->d_n0, n0, (size_t)n0_count * 4, hipMemcpyHostToDevice, h->stream));
+    if (h->dm->soft_device(h->d_syms, n_frames, h->d_n0, n0_count, h->d_llr, h->stream)) return fail(DVBS2_EDEVICE, h->dm->error());
+    HCHK(hipMemcpyAsync(llr_out, h->d_llr, (size_t)n_frames * h->dm->n_llr(), hipMemcpyDeviceToHost, h->stream));
+    HCHK(hipStreamSynchronize(h->stream));
+    return DVBS2_OK;
+    API_CATCH
+}
+
+int dvbs2_demap_estimate_snr_device(dvbs2_demap_t* h, const float* d_syms, int n_frames, float* d_snr_lin, void* stream)
+{
+    API_TRY
+    if (!h) return fail(DVBS2_EINVAL, "null handle");
+    if (n_frames < 0 || (n_frames && (!d_syms || !d_snr_lin))) return fail(DVBS2_EINVAL, "bad argument");
+    if (n_frames > h->dm->max_frames()) return fail(DVBS2_ESIZE, "n_frames exceeds max_frames");
+    if (h->dm->snr_device(d_syms, n_frames, d_snr_lin, (hipStream_t)stream)) return fail(DVBS2_EDEVICE, h->dm->error());
+    return DVBS2_OK;
+    API_CATCH
+}
+
+int dvbs2_demap_estimate_snr(dvbs2_demap_t* h, const float* syms, int n_frames, float* snr_lin)
+{
+    API_TRY
+    if (!h) return fail(DVBS2_EINVAL, "null handle");
+    if (n_frames < 0 || (n_frames && (!syms || !snr_lin))) return fail(DVBS2_EINVAL, "bad argument");
+    if (n_frames > h->dm->max_frames()) return fail(DVBS2_ESIZE, "n_frames exceeds max_frames");
+    if (n_frames == 0) return DVBS2_OK;
+    if (int rc = demap_stage(h, syms, n_frames)) return rc;
+    if (h->dm->snr_device(h->d_syms, n_frames, h->d_snr, h->stream)) return fail(DVBS2_EDEVICE, h->dm->error());
+    HCHK(hipMemcpyAsync(snr_lin, h->d_snr, (size_t)n_frames * 4, hipMemcpyDeviceToHost, h->stream));
+    HCHK(hipStreamSynchronize(h->stream));
+    return DVBS2_OK;
+    API_CATCH
+}
+
+} // extern "C"
+
+/* ------------------------------------------------------------------ chain */
+struct dvbs2_chain {
+    dvbs2_demap_t* dm = nullptr; dvbs2_ldpc_t* ldpc = nullptr; dvbs2_bch_t* bch = nullptr;
+    int8_t* d_llr = nullptr; uint8_t* d_bits = nullptr; int32_t* d_corr = nullptr;
+    int device = 0, max_frames = 0, n_llr = 0, ldpc_bytes = 0, msg_bytes = 0;
+};
+
+extern "C" {
+
+void dvbs2_chain_destroy(dvbs2_chain_t* h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    dvbs2_demap_destroy(h->dm); dvbs2_ldpc_destroy(h->ldpc); dvbs2_bch_destroy(h->bch);
+    (void)hipFree(h->d_llr); (void)hipFree(h->d_bits); (void)hipFree(h->d_corr);
+    delete h;
+}
+
+int dvbs2_chain_create(dvbs2_chain_t** h, int standard, int framesize, int rate, int constellation, int group_size, int max_frames, int device)
+{
+    API_TRY
+    if (!h) return fail(DVBS2_EINVAL, "null handle pointer");
+    *h = nullptr;
+    dvbs2_chain* o = new (std::nothrow) dvbs2_chain();
+    if (!o) return fail(DVBS2_EDEVICE, "out of memory");
+    o->device = device; o->max_frames = max_frames;
+    int rc = dvbs2_demap_create(&o->dm, framesize, rate, constellation, max_frames, device);
+    if (rc == DVBS2_OK) rc = dvbs2_ldpc_create(&o->ldpc, standard, framesize, rate, group_size, max_frames, device);
+    if (rc == DVBS2_OK) rc = dvbs2_bch_create(&o->bch, standard, framesize, rate, max_frames, device);
+    if (rc != DVBS2_OK) { std::string keep = g_err; dvbs2_chain_destroy(o); return fail(rc, keep); }
+    o->n_llr = o->dm->dm->n_llr();
+    o->ldpc_bytes = o->ldpc->dec->out_bits_message() / 8;
+    o->msg_bytes = o->bch->dec->code().k / 8;
+    if (o->ldpc->dec->N() != o->n_llr || o->ldpc_bytes != o->bch->dec->code().n / 8) { dvbs2_chain_destroy(o); return fail(DVBS2_EINVAL, "inconsistent chain sizes"); }
+    hipError_t e = hipSetDevice(device);
+    if (e == hipSuccess) e = hipMalloc(&o->d_llr, (size_t)max_frames * o->n_llr);
+    if (e == hipSuccess) e = hipMalloc(&o->d_bits, (size_t)max_frames * o->ldpc_bytes);
+    if (e == hipSuccess) e = hipMalloc(&o->d_corr, (size_t)max_frames * 4);
+    if (e != hipSuccess) { dvbs2_chain_destroy(o); return fail(DVBS2_EDEVICE, hipGetErrorString(e)); }
+    *h = o;
+    return DVBS2_OK;
+    API_CATCH
+}
+
+int dvbs2_chain_params(const dvbs2_chain_t* h, int* n_syms, int* msg_bytes)
+{
+    if (!h) return fail(DVBS2_EINVAL, "null handle");
+    if (n_syms) *n_syms = h->dm->dm->n_syms();
+    if (msg_bytes) *msg_bytes = h->msg_bytes;
+    return DVBS2_OK;
+}
+
+int dvbs2_chain_decode_device(dvbs2_chain_t* h, const float* d_syms, int n_frames, const float* d_n0, int n0_count,
+                              int max_trials, uint8_t* d_msg, int32_t* d_ldpc_ret, int32_t* d_bch_corr, void* stream)
+{
+    API_TRY
+    if (!h) return fail(DVBS2_EINVAL, "null handle");
+    if (n_frames > h->max_frames) return fail(DVBS2_ESIZE, "n_frames exceeds max_frames");
+    int rc = dvbs2_demap_soft_device(h->dm, d_syms, n_frames, d_n0, n0_count, h->d_llr, stream);
+    if (rc == DVBS2_OK) rc = dvbs2_ldpc_decode_device(h->ldpc, h->d_llr, n_frames, max_trials, DVBS2_OM_MESSAGE, h->d_bits, nullptr, d_ldpc_ret, stream);
+    if (rc == DVBS2_OK) rc = dvbs2_bch_decode_device(h->bch, h->d_bits, n_frames, d_msg, d_bch_corr ? d_bch_corr : h->d_corr, stream);
+    return rc;
+    API_CATCH
 }
 
 } // extern "C"

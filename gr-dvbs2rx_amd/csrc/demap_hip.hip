@@ -1,0 +1,145 @@
+// demap_hip.hip -- soft demapper kernels. Streaming, HBM-bound: 8 bytes in per symbol, n_mod bytes out.
+//
+// Arithmetic restated (all float, no FMA contraction: the file is compiled with -ffp-contract=off and the
+// products below use explicit round-to-nearest intrinsics):
+//   QPSK  lib/qpsk.h:208-214: scalar = (float)(2*sqrt(2) / N0); out = sat8(rint(x * scalar)) over the 2*n_syms
+//         floats (volk_32f_s32f_convert_8i; VOLK is not part of the reference tree -- see oracle/demap_oracle.c).
+//   8PSK  lib/psk.hh:143-150 with quantize :123-131 and rot :113; precision = (float)(4.0 / N0)
+//         (lib/xfecframe_demapper_cb_impl.cc:148); column de-interleave :162-176.
+#include "demap_hip.h"
+#include <cmath>
+#include "../../include/dvbs2_fec_hip.h"
+
+namespace dvbs2 {
+
+__device__ __forceinline__ int8_t sat8_rint(float v)
+{
+    if (v > 127.0f) return 127;
+    if (v < -128.0f) return -128;
+    return (int8_t)rintf(v);
+}
+
+__global__ void demap_qpsk_kernel(const float4* __restrict__ syms, const float* __restrict__ n0, int n0_count,
+                                  uint32_t* __restrict__ out, int quads_per_frame, int n_frames)
+{
+    const int f = blockIdx.y;
+    const float N0 = n0[n0_count > 1 ? f : 0];
+    const float scalar = (float)(2.0 * 1.41421356237309504880 / (double)N0);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < quads_per_frame; i += gridDim.x * blockDim.x) {
+        const float4 v = syms[(size_t)f * quads_per_frame + i]; // two symbols
+        const uint32_t b0 = (uint8_t)sat8_rint(__fmul_rn(v.x, scalar)), b1 = (uint8_t)sat8_rint(__fmul_rn(v.y, scalar));
+        const uint32_t b2 = (uint8_t)sat8_rint(__fmul_rn(v.z, scalar)), b3 = (uint8_t)sat8_rint(__fmul_rn(v.w, scalar));
+        out[(size_t)f * quads_per_frame + i] = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
+    }
+}
+
+__device__ __forceinline__ int8_t quant8(float dist_prec, float value)
+{
+    value = __fmul_rn(value, dist_prec);
+    value = rintf(value);
+    value = fminf(fmaxf(value, -128.0f), 127.0f);
+    return (int8_t)value;
+}
+
+__global__ void demap_8psk_kernel(const float2* __restrict__ syms, const float* __restrict__ n0, int n0_count,
+                                  int8_t* __restrict__ out, int n_syms, int ra0, int ra1, int ra2, float rr, float ri)
+{
+    const int f = blockIdx.y;
+    const float N0 = n0[n0_count > 1 ? f : 0];
+    const float precision = (float)(4.0 / (double)N0);
+    const float sin_pi_8 = 0.38268343236508977173f;
+    const float DIST = 2 * sin_pi_8;
+    const float dp = __fmul_rn(DIST, precision);
+    const float rcp_sqrt_2 = 0.70710678118654752440f;
+    int8_t* o = out + (size_t)f * 3 * n_syms;
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n_syms; j += gridDim.x * blockDim.x) {
+        const float2 c = syms[(size_t)f * n_syms + j];
+        const float cr = __fsub_rn(__fmul_rn(c.x, rr), __fmul_rn(c.y, ri));
+        const float ci = __fadd_rn(__fmul_rn(c.x, ri), __fmul_rn(c.y, rr));
+        o[ra1 + j] = quant8(dp, cr);
+        o[ra2 + j] = quant8(dp, ci);
+        o[ra0 + j] = quant8(dp, __fmul_rn(rcp_sqrt_2, __fsub_rn(fabsf(cr), fabsf(ci))));
+    }
+}
+
+__global__ void demap_snr_kernel(const float2* __restrict__ syms, float* __restrict__ snr, int n_syms, int constellation,
+                                 float rr, float ri)
+{
+    __shared__ float ssp[256], snp[256];
+    const int f = blockIdx.x, tid = threadIdx.x;
+    const float rs2 = 0.70710678118654752440f;
+    float sp = 0, np = 0;
+    for (int j = tid; j < n_syms; j += blockDim.x) {
+        const float2 c = syms[(size_t)f * n_syms + j];
+        float sr, si;
+        if (constellation == DVBS2_MOD_QPSK) { sr = c.x >= 0 ? rs2 : -rs2; si = c.y >= 0 ? rs2 : -rs2; }
+        else {
+            const float cr = c.x * rr - c.y * ri, ci = c.x * ri + c.y * rr;
+            const int b1 = cr < 0 ? -1 : 1, b2 = ci < 0 ? -1 : 1, b0 = fabsf(cr) < fabsf(ci) ? -1 : 1;
+            const int idx = (((b0 + 1) << 1) ^ 0x4) | ((b1 + 1) ^ 0x2) | (((b2 + 1) >> 1) ^ 0x1);
+            const float m8r[8] = { rs2, 1, -1, -rs2, 0, rs2, -rs2, 0 }, m8i[8] = { rs2, 0, 0, -rs2, 1, -rs2, rs2, -1 };
+            sr = m8r[idx]; si = m8i[idx];
+        }
+        const float er = c.x - sr, ei = c.y - si;
+        sp += sr * sr + si * si; np += er * er + ei * ei;
+    }
+    ssp[tid] = sp; snp[tid] = np;
+    __syncthreads();
+    for (int s = 128; s; s >>= 1) { if (tid < s) { ssp[tid] += ssp[tid + s]; snp[tid] += snp[tid + s]; } __syncthreads(); }
+    if (tid == 0) { float n = snp[0]; if (!(n > 0)) n = 1e-12f; snr[f] = ssp[0] / n; }
+}
+
+DemapperHip::DemapperHip(int framesize, int rate, int constellation, int max_frames, int device)
+    : constellation_(constellation), max_frames_(max_frames), device_(device)
+{
+    n_llr_ = framesize == DVBS2_FECFRAME_NORMAL ? 64800 : framesize == DVBS2_FECFRAME_MEDIUM ? 32400 : 16200;
+    if (constellation == DVBS2_MOD_QPSK) n_mod_ = 2;
+    else if (constellation == DVBS2_MOD_8PSK) {
+        n_mod_ = 3;
+        // rate enumerators: C3_5 = 4; C25_36 = 26, C13_18 = 28, C7_15 = 38, C8_15 = 39, C26_45 = 19 (dvb_config.h:20-72)
+        if (rate == 4) order_ = 1;                                                              // "210"
+        else if (rate == 26 || rate == 28 || rate == 38 || rate == 39 || rate == 19) order_ = 2; // "102"
+        else order_ = 0;                                                                         // "012"
+    } else { err_ = "Unsupported constellation"; return; }
+    if (max_frames_ < 1) { err_ = "bad max_frames"; return; }
+}
+
+int DemapperHip::soft_device(const float* d_syms, int n_frames, const float* d_n0, int n0_count, int8_t* d_llr, hipStream_t stream)
+{
+    if (!ok()) return -1;
+    if (n_frames < 0 || n_frames > max_frames_) { err_ = "n_frames exceeds max_frames"; return -1; }
+    if (n_frames == 0) return 0;
+    if (hipSetDevice(device_) != hipSuccess) { err_ = "hipSetDevice failed"; return -1; }
+    if (constellation_ == DVBS2_MOD_QPSK) {
+        const int quads = n_llr_ / 4;
+        hipLaunchKernelGGL(demap_qpsk_kernel, dim3((quads + 255) / 256, n_frames), dim3(256), 0, stream,
+                           reinterpret_cast<const float4*>(d_syms), d_n0, n0_count, reinterpret_cast<uint32_t*>(d_llr), quads, n_frames);
+    } else {
+        const int rows = n_syms();
+        int ra0 = 0, ra1 = rows, ra2 = 2 * rows;
+        if (order_ == 1) { ra0 = 2 * rows; ra1 = rows; ra2 = 0; }
+        else if (order_ == 2) { ra0 = rows; ra1 = 0; ra2 = 2 * rows; }
+        const float rr = (float)std::cos(-M_PI / 8), ri = (float)std::sin(-M_PI / 8); // (complexf) exp(-j pi/8)
+        hipLaunchKernelGGL(demap_8psk_kernel, dim3((rows + 255) / 256, n_frames), dim3(256), 0, stream,
+                           reinterpret_cast<const float2*>(d_syms), d_n0, n0_count, d_llr, rows, ra0, ra1, ra2, rr, ri);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { err_ = std::string("demap kernel launch: ") + hipGetErrorString(e); return -1; }
+    return 0;
+}
+
+int DemapperHip::snr_device(const float* d_syms, int n_frames, float* d_snr, hipStream_t stream)
+{
+    if (!ok()) return -1;
+    if (n_frames < 0 || n_frames > max_frames_) { err_ = "n_frames exceeds max_frames"; return -1; }
+    if (n_frames == 0) return 0;
+    if (hipSetDevice(device_) != hipSuccess) { err_ = "hipSetDevice failed"; return -1; }
+    const float rr = (float)std::cos(-M_PI / 8), ri = (float)std::sin(-M_PI / 8);
+    hipLaunchKernelGGL(demap_snr_kernel, dim3(n_frames), dim3(256), 0, stream,
+                       reinterpret_cast<const float2*>(d_syms), d_snr, n_syms(), constellation_, rr, ri);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { err_ = std::string("snr kernel launch: ") + hipGetErrorString(e); return -1; }
+    return 0;
+}
+
+} // namespace dvbs2

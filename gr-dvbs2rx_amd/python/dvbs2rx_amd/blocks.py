@@ -13,7 +13,7 @@ import numpy as np
 from . import capi
 from .capi import lib, check
 
-__all__ = ["get_fec_info", "rate_id", "LdpcDecoder", "ldpc_table_info", "ldpc_layer_info"]
+__all__ = ["get_fec_info", "rate_id", "LdpcDecoder", "BchDecoder", "Demapper", "FecChain", "ldpc_table_info", "ldpc_layer_info"]
 
 DEFAULT_TRIALS = 25  # reference lib/ldpc_decoder_bb_impl.cc:391
 
@@ -119,3 +119,124 @@ class LdpcDecoder:
         ms, n = C.c_double(), C.c_int()
         check(lib.dvbs2_ldpc_profile(self._h, 1 if enable else 0, ms, n))
         return ms.value, n.value
+
+
+class BchDecoder:
+    """bch_decoder_bb's compute (reference lib/bch_decoder_bb_impl.cc:84-117): n/8-byte codewords -> k/8-byte messages."""
+
+    def __init__(self, standard=capi.STANDARD_DVBS2, framesize=capi.FECFRAME_NORMAL, rate="C1_2", max_frames=64,
+                 device=0, raw=None):
+        self._h = C.c_void_p()
+        if raw is not None:
+            m, prim, t, n = raw
+            check(lib.dvbs2_bch_create_raw(C.byref(self._h), m, prim, t, n, max_frames, device))
+        else:
+            check(lib.dvbs2_bch_create(C.byref(self._h), standard, framesize, rate_id(rate), max_frames, device))
+        v = [C.c_int() for _ in range(3)]
+        check(lib.dvbs2_bch_params(self._h, *v))
+        self.n, self.k, self.t = (x.value for x in v)
+        # counters behind get_frame_count / get_error_count (lib/bch_decoder_bb_impl.h:46-47)
+        self.frame_cnt = 0
+        self.frame_error_cnt = 0
+
+    def close(self):
+        if self._h:
+            lib.dvbs2_bch_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def genpoly(self):
+        g = np.zeros(256, np.uint8)
+        deg = check(lib.dvbs2_bch_genpoly(self._h, g.ctypes.data, 256))
+        return g[:deg + 1].copy()
+
+    def work(self, cw):
+        cw = np.ascontiguousarray(cw, dtype=np.uint8)
+        nf = cw.shape[0]
+        assert cw.shape == (nf, self.n // 8)
+        msg = np.empty((nf, self.k // 8), np.uint8)
+        corr = np.empty(nf, np.int32)
+        check(lib.dvbs2_bch_decode(self._h, cw.ctypes.data, nf, msg.ctypes.data, corr.ctypes.data))
+        self.frame_cnt += nf
+        self.frame_error_cnt += int((corr == -1).sum())
+        return msg, corr
+
+    def work_device(self, d_cw, n_frames, d_msg, d_corr, stream=0):
+        check(lib.dvbs2_bch_decode_device(self._h, d_cw, n_frames, d_msg, d_corr, stream or None))
+
+
+class Demapper:
+    """xfecframe_demapper_cb's compute (reference lib/xfecframe_demapper_cb_impl.cc:101-186)."""
+
+    def __init__(self, framesize=capi.FECFRAME_NORMAL, rate="C1_2", constellation=capi.MOD_QPSK, max_frames=64, device=0):
+        self._h = C.c_void_p()
+        check(lib.dvbs2_demap_create(C.byref(self._h), framesize, rate_id(rate), constellation, max_frames, device))
+        v = [C.c_int() for _ in range(4)]
+        check(lib.dvbs2_demap_params(self._h, *v))
+        self.n_syms, self.n_llr, self.n_mod, self.column_order = (x.value for x in v)
+
+    def close(self):
+        if self._h:
+            lib.dvbs2_demap_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def work(self, syms, n0):
+        """syms: (n_frames, n_syms) complex64; n0: scalar or (n_frames,) float32 -> (n_frames, n_llr) int8."""
+        syms = np.ascontiguousarray(syms, dtype=np.complex64)
+        nf = syms.shape[0]
+        assert syms.shape == (nf, self.n_syms)
+        n0 = np.atleast_1d(np.asarray(n0, np.float32))
+        out = np.empty((nf, self.n_llr), np.int8)
+        check(lib.dvbs2_demap_soft(self._h, syms.ctypes.data, nf, n0.ctypes.data, len(n0), out.ctypes.data))
+        return out
+
+    def estimate_snr(self, syms):
+        syms = np.ascontiguousarray(syms, dtype=np.complex64)
+        nf = syms.shape[0]
+        snr = np.empty(nf, np.float32)
+        check(lib.dvbs2_demap_estimate_snr(self._h, syms.ctypes.data, nf, snr.ctypes.data))
+        return snr
+
+    def work_device(self, d_syms, n_frames, d_n0, n0_count, d_llr, stream=0):
+        check(lib.dvbs2_demap_soft_device(self._h, d_syms, n_frames, d_n0, n0_count, d_llr, stream or None))
+
+
+class FecChain:
+    """demapper -> LDPC (OM_MESSAGE) -> BCH on the device, as wired in apps/dvbs2-rx:853-863."""
+
+    def __init__(self, standard=capi.STANDARD_DVBS2, framesize=capi.FECFRAME_NORMAL, rate="C3_4",
+                 constellation=capi.MOD_8PSK, group_size=32, max_frames=64, max_trials=0, device=0):
+        self._h = C.c_void_p()
+        check(lib.dvbs2_chain_create(C.byref(self._h), standard, framesize, rate_id(rate), constellation,
+                                     group_size, max_frames, device))
+        a, b = C.c_int(), C.c_int()
+        check(lib.dvbs2_chain_params(self._h, a, b))
+        self.n_syms, self.msg_bytes = a.value, b.value
+        self.group_size = group_size
+        self.max_trials = DEFAULT_TRIALS if max_trials == 0 else max_trials
+
+    def close(self):
+        if self._h:
+            lib.dvbs2_chain_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def work_device(self, d_syms, n_frames, d_n0, n0_count, d_msg, d_ldpc_ret=0, d_bch_corr=0, stream=0):
+        check(lib.dvbs2_chain_decode_device(self._h, d_syms, n_frames, d_n0, n0_count, self.max_trials, d_msg,
+                                            d_ldpc_ret or None, d_bch_corr or None, stream or None))

@@ -49,6 +49,24 @@ SYMBOLS = {
     "dvbs2_ldpc_decode": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "dvbs2_ldpc_decode_device": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "dvbs2_ldpc_profile": (_i, [_vp, _i, C.POINTER(C.c_double), _ip]),
+    "dvbs2_bch_create": (_i, [C.POINTER(_vp), _i, _i, _i, _i, _i]),
+    "dvbs2_bch_create_raw": (_i, [C.POINTER(_vp), _i, C.c_uint32, _i, _i, _i, _i]),
+    "dvbs2_bch_destroy": (None, [_vp]),
+    "dvbs2_bch_params": (_i, [_vp, _ip, _ip, _ip]),
+    "dvbs2_bch_genpoly": (_i, [_vp, _vp, _i]),
+    "dvbs2_bch_decode": (_i, [_vp, _vp, _i, _vp, _vp]),
+    "dvbs2_bch_decode_device": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
+    "dvbs2_demap_create": (_i, [C.POINTER(_vp), _i, _i, _i, _i, _i]),
+    "dvbs2_demap_destroy": (None, [_vp]),
+    "dvbs2_demap_params": (_i, [_vp, _ip, _ip, _ip, _ip]),
+    "dvbs2_demap_soft": (_i, [_vp, _vp, _i, _vp, _i, _vp]),
+    "dvbs2_demap_soft_device": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp]),
+    "dvbs2_demap_estimate_snr": (_i, [_vp, _vp, _i, _vp]),
+    "dvbs2_demap_estimate_snr_device": (_i, [_vp, _vp, _i, _vp, _vp]),
+    "dvbs2_chain_create": (_i, [C.POINTER(_vp), _i, _i, _i, _i, _i, _i, _i]),
+    "dvbs2_chain_destroy": (None, [_vp]),
+    "dvbs2_chain_params": (_i, [_vp, _ip, _ip]),
+    "dvbs2_chain_decode_device": (_i, [_vp, _vp, _i, _vp, _i, _i, _vp, _vp, _vp, _vp]),
 }
 
 if not os.path.exists(LIB_PATH):

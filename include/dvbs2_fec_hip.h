@@ -97,6 +97,70 @@ int dvbs2_ldpc_decode_device(dvbs2_ldpc_t* h, const int8_t* d_llr_in, int n_fram
  * enable != 0 starts/reset accumulation; reads back total milliseconds and launch count. */
 int dvbs2_ldpc_profile(dvbs2_ldpc_t* h, int enable, double* total_ms, int* launches);
 
+/* ---- BCH: replaces bch_codec<uint32_t, bitset256_t>::decode(u8_cptr_t, u8_ptr_t) as called by
+ * bch_decoder_bb_impl (reference lib/bch.h:151, lib/bch_decoder_bb_impl.cc:58-66, :94-113) ----
+ * The field is chosen like the block does: GF(2^16) x^16+x^5+x^3+x^2+1 for normal, GF(2^14) x^14+x^5+x^3+x+1
+ * for short, GF(2^15) x^15+x^5+x^3+x^2+1 for medium frames; (n, t) from get_fec_info. */
+typedef struct dvbs2_bch dvbs2_bch_t;
+int dvbs2_bch_create(dvbs2_bch_t** h, int standard, int framesize, int rate, int max_frames, int device);
+/* any binary BCH code over GF(2^m), 3 <= m <= 16, t <= 12, n (0 = 2^m - 1) and k multiples of 8 */
+int dvbs2_bch_create_raw(dvbs2_bch_t** h, int m, uint32_t prim_poly, int t, int n, int max_frames, int device);
+void dvbs2_bch_destroy(dvbs2_bch_t* h);
+int dvbs2_bch_params(const dvbs2_bch_t* h, int* n, int* k, int* t);
+/* generator polynomial coefficients (one byte per coefficient, index = power of x), host only;
+ * returns deg g or <0. gen may be NULL. */
+int dvbs2_bch_genpoly(const dvbs2_bch_t* h, uint8_t* gen, int max_coefs);
+/*
+ * cw           n_frames * n/8 bytes, network bit order (first bit = x^(n-1), lib/bch.cc:436-449)
+ * msg          n_frames * k/8 bytes: the systematic part with the located errors flipped (lib/bch.cc:471,445-450)
+ * corrections  per frame: number of corrected bits (>= 0), -1 = more than t errors / roots not all found
+ *              (the block counts it in d_frame_error_cnt, lib/bch_decoder_bb_impl.cc:101-107), -2 = the
+ *              reference would have thrown here (std::out_of_range from galois_field::get_exponent(0),
+ *              lib/gf.h:110 via lib/bch.cc:359-367; or "Error location number out of range", lib/bch.cc:443-444)
+ */
+int dvbs2_bch_decode(dvbs2_bch_t* h, const uint8_t* cw, int n_frames, uint8_t* msg, int32_t* corrections);
+int dvbs2_bch_decode_device(dvbs2_bch_t* h, const uint8_t* d_cw, int n_frames, uint8_t* d_msg,
+                            int32_t* d_corrections, void* stream);
+
+/* ---- soft demapper: replaces QpskConstellation::demap_soft (reference lib/qpsk.h:208-214) and the
+ * PhaseShiftKeying<8>::soft loop + column de-interleave (lib/psk.hh:143-150,
+ * lib/xfecframe_demapper_cb_impl.cc:152-176) inside xfecframe_demapper_cb_impl::general_work ----
+ * constellation: DVBS2_MOD_QPSK or DVBS2_MOD_8PSK; anything else fails with DVBS2_EINVAL
+ * ("Unsupported constellation", lib/xfecframe_demapper_cb_impl.cc:70-72). */
+typedef struct dvbs2_demap dvbs2_demap_t;
+int dvbs2_demap_create(dvbs2_demap_t** h, int framesize, int rate, int constellation, int max_frames, int device);
+void dvbs2_demap_destroy(dvbs2_demap_t* h);
+/* symbols per frame (d_xfecframe_len), LLRs per frame (d_fecframe_len), bits per symbol, 8PSK column
+ * order (0 = "012", 1 = "210", 2 = "102") */
+int dvbs2_demap_params(const dvbs2_demap_t* h, int* n_syms, int* n_llr, int* n_mod, int* column_order);
+/*
+ * syms      n_frames * n_syms complex symbols as interleaved (re, im) floats (gr_complex layout)
+ * n0        noise energy N0 = Es/SNR (the block's d_N0, lib/xfecframe_demapper_cb_impl.cc:146-148,313-315):
+ *           n0_count == 1: one value for all frames; n0_count == n_frames: one per frame
+ * llr_out   n_frames * n_llr int8 LLRs, natural bit order (8PSK: de-interleaved)
+ */
+int dvbs2_demap_soft(dvbs2_demap_t* h, const float* syms, int n_frames, const float* n0, int n0_count,
+                     int8_t* llr_out);
+int dvbs2_demap_soft_device(dvbs2_demap_t* h, const float* d_syms, int n_frames, const float* d_n0,
+                            int n0_count, int8_t* d_llr_out, void* stream);
+/* pre-decoder linear SNR estimate per frame (lib/xfecframe_demapper_cb_impl.cc:128-149, lib/qpsk.h:240-244).
+ * Float reduction in a different order than the reference: equal within tolerance, not bit-exact. */
+int dvbs2_demap_estimate_snr(dvbs2_demap_t* h, const float* syms, int n_frames, float* snr_lin);
+int dvbs2_demap_estimate_snr_device(dvbs2_demap_t* h, const float* d_syms, int n_frames, float* d_snr_lin,
+                                    void* stream);
+
+/* ---- whole chain on the device: xfecframe_demapper_cb -> ldpc_decoder_bb (OM_MESSAGE) -> bch_decoder_bb,
+ * as wired in apps/dvbs2-rx:853-863; intermediate LLRs and LDPC output stay in HBM ---- */
+typedef struct dvbs2_chain dvbs2_chain_t;
+int dvbs2_chain_create(dvbs2_chain_t** h, int standard, int framesize, int rate, int constellation,
+                       int group_size, int max_frames, int device);
+void dvbs2_chain_destroy(dvbs2_chain_t* h);
+/* bytes per frame out (bch k / 8), symbols per frame in */
+int dvbs2_chain_params(const dvbs2_chain_t* h, int* n_syms, int* msg_bytes);
+/* d_msg: n_frames * bch_k/8; d_ldpc_ret (nullable): one per LDPC group; d_bch_corr (nullable -> internal): per frame */
+int dvbs2_chain_decode_device(dvbs2_chain_t* h, const float* d_syms, int n_frames, const float* d_n0, int n0_count,
+                              int max_trials, uint8_t* d_msg, int32_t* d_ldpc_ret, int32_t* d_bch_corr, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -145,3 +145,113 @@ def llr_codeword_awgn(table, n_frames, seed, amp=6.0, sigma=4.0, info=None):
     cw = ldpc_encode(table, info)
     y = amp * (1.0 - 2.0 * cw) + sigma * rng.normal(0.0, 1.0, cw.shape)
     return np.clip(np.rint(y), -128, 127).astype(np.int8), cw
+
+
+def make_input(table, kind, n_frames, seed=0, amp=6.0, sigma=4.0):
+    """Deterministic LDPC test inputs by name (used by the golden fixtures)."""
+    N = ldpc_info(table)[0]
+    if kind == "noise":
+        return llr_noise(n_frames, N, seed)
+    if kind == "awgn":
+        return llr_codeword_awgn(table, n_frames, seed, amp=amp, sigma=sigma)[0]
+    if kind == "sat":
+        rng = np.random.default_rng(seed)
+        return rng.choice(np.array([-128, -127, 127, 126, 0], np.int8), (n_frames, N))
+    if kind == "zero":
+        return np.zeros((n_frames, N), np.int8)
+    raise ValueError(kind)
+
+
+# ------------------------------------------------------------------ BCH helpers (oracle)
+class OracleBch:
+    def __init__(self, m, prim_poly, t, n=0):
+        self.o = oracle()
+        self.h = self.o.oracle_bch_new(m, prim_poly, t, n)
+        self.n, self.k, self.t, self.m = self.o.oracle_bch_n(self.h), self.o.oracle_bch_k(self.h), t, m
+
+    def __del__(self):
+        try:
+            self.o.oracle_bch_free(self.h)
+        except Exception:
+            pass
+
+    def genpoly_int(self):
+        deg = self.o.oracle_bch_gdeg(self.h)
+        g = np.zeros(deg + 1, np.uint8)
+        self.o.oracle_bch_genpoly(self.h, ptr(g))
+        return sum(int(b) << i for i, b in enumerate(g))
+
+    def alpha(self, i):
+        return self.o.oracle_bch_alpha(self.h, i)
+
+    def minpoly(self, e):
+        return self.o.oracle_bch_minpoly(self.h, e)
+
+    def encode_bits(self, msg_bits):
+        cw = np.zeros(self.n, np.uint8)
+        self.o.oracle_bch_encode_bits(self.h, ptr(np.ascontiguousarray(msg_bits, np.uint8)), ptr(cw))
+        return cw
+
+    def syndrome_bits(self, cw_bits):
+        S = np.zeros(2 * self.t, np.uint32)
+        n = self.o.oracle_bch_syndrome_bits(self.h, ptr(np.ascontiguousarray(cw_bits, np.uint8)), ptr(S))
+        return S[:n]
+
+    def err_loc(self, S):
+        sigma = np.zeros(64, np.uint32)
+        deg = self.o.oracle_bch_err_loc_poly(self.h, ptr(np.ascontiguousarray(S, np.uint32)), ptr(sigma))
+        nums = np.zeros(32, np.uint32)
+        cnt = self.o.oracle_bch_err_loc_numbers(self.h, ptr(sigma), deg, ptr(nums))
+        return sigma[:deg + 1], nums[:max(cnt, 0)], cnt
+
+    def encode_bytes(self, msg):
+        msg = np.ascontiguousarray(msg, np.uint8)
+        cw = np.zeros((msg.shape[0], self.n // 8), np.uint8)
+        for f in range(msg.shape[0]):
+            self.o.oracle_bch_encode_bytes(self.h, ptr(msg[f]), ptr(cw[f]))
+        return cw
+
+    def decode_bytes(self, cw):
+        cw = np.ascontiguousarray(cw, np.uint8)
+        msg = np.zeros((cw.shape[0], self.k // 8), np.uint8)
+        ret = np.zeros(cw.shape[0], np.int32)
+        for f in range(cw.shape[0]):
+            ret[f] = self.o.oracle_bch_decode_bytes(self.h, ptr(cw[f]), ptr(msg[f]))
+        return msg, ret
+
+
+BCH_FIELDS = {1: (16, 0b10000000000101101), 0: (14, 0b100000000101011), 2: (15, 0b1000000000101101)}  # by framesize id
+
+
+def flip_bits(cw_bytes, positions):
+    """Flip stream bit positions (0 = first transmitted bit) in a packed byte row (copy)."""
+    out = cw_bytes.copy()
+    for p in positions:
+        out[p // 8] ^= np.uint8(1 << (7 - p % 8))
+    return out
+
+
+# ------------------------------------------------------------------ demapper helpers (oracle)
+def oracle_demap(syms, n0, constellation, order=0):
+    syms = np.ascontiguousarray(syms, np.complex64)
+    nf, ns = syms.shape
+    n0 = np.broadcast_to(np.asarray(n0, np.float32), (nf,))
+    nmod = 2 if constellation == 4 else 3
+    out = np.zeros((nf, ns * nmod), np.int8)
+    for f in range(nf):
+        if constellation == 4:
+            oracle().oracle_demap_qpsk(ptr(syms[f]), ns, float(n0[f]), ptr(out[f]))
+        else:
+            oracle().oracle_demap_8psk(ptr(syms[f]), ns, float(n0[f]), order, ptr(out[f]))
+    return out
+
+
+M8PSK = np.array([np.sqrt(.5) * (1 + 1j), 1, -1, np.sqrt(.5) * (-1 - 1j), 1j, np.sqrt(.5) * (1 - 1j),
+                  np.sqrt(.5) * (-1 + 1j), -1j], np.complex64)
+
+
+def map_8psk(bits3):
+    """bits3: (..., 3) bits (b0 b1 b2 of lib/psk.hh:152-157 in +-1 -> index form) -> constellation point."""
+    b = 1 - 2 * bits3.astype(np.int32)  # bit 0 -> +1, bit 1 -> -1 (positive LLR = bit 0)
+    idx = (((b[..., 0] + 1) << 1) ^ 0x4) | ((b[..., 1] + 1) ^ 0x2) | (((b[..., 2] + 1) >> 1) ^ 0x1)
+    return M8PSK[idx]

@@ -1,0 +1,175 @@
+"""CPU-only: pins the plain-C oracle (oracle/) to the reference's own known-answer tests and golden digests, and
+checks the host logic of the product library (parameter map, exported C symbols). No GPU compute here."""
+import ctypes as C
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+import fec_testlib as T
+from dvbs2rx_amd import capi, get_fec_info
+
+GOLD = os.path.join(T.ROOT, "tests", "golden")
+KAT = json.load(open(os.path.join(GOLD, "bch_kat.json")))
+
+
+# ------------------------------------------------------------------ GF / BCH (lib/qa_gf.cc, lib/qa_bch.cc)
+@pytest.mark.parametrize("entry", KAT["minpoly"], ids=lambda e: f"GF2^{e['m']}")
+def test_dvbs2_minimal_polynomials(entry):
+    b = T.OracleBch(entry["m"], entry["prim_poly"], 1)
+    for i, want in enumerate(entry["polys"], start=1):
+        assert b.minpoly(2 * i - 1) == want
+
+
+def test_generator_polynomials():
+    for e in KAT["gen_m4"]:
+        assert T.OracleBch(4, 0b10011, e["t"]).genpoly_int() == e["g"]
+    for e in KAT["gen_m6"]:
+        b = T.OracleBch(6, 0b1000011, e["t"])
+        assert b.genpoly_int() == e["g"] and b.k == e["k"]
+
+
+def test_all_codewords_15_7():
+    b = T.OracleBch(4, 0b10011, 2)
+    assert (b.n, b.k) == (15, 7)
+    for msg, want in enumerate(KAT["codewords_15_7"]):
+        bits = np.array([(msg >> (6 - i)) & 1 for i in range(7)], np.uint8)
+        cw = b.encode_bits(bits)
+        assert int("".join(map(str, cw)), 2) == want
+
+
+def test_syndrome_and_error_locator_kats():
+    s = KAT["syndrome"]
+    b = T.OracleBch(s["m"], s["prim_poly"], s["t"])
+    rx = np.array([(s["rx"] >> (b.n - 1 - i)) & 1 for i in range(b.n)], np.uint8)
+    assert b.syndrome_bits(rx).tolist() == [b.alpha(e) for e in s["alpha_exps"]]
+    e = KAT["errloc"]
+    b = T.OracleBch(e["m"], e["prim_poly"], e["t"])
+    rx = np.array([(e["rx"] >> (b.n - 1 - i)) & 1 for i in range(b.n)], np.uint8)
+    S = b.syndrome_bits(rx)
+    assert S.tolist() == [b.alpha(x) for x in e["syndrome_alpha_exps"]]
+    sigma, nums, cnt = b.err_loc(S)
+    assert sigma.tolist() == [0 if x is None else b.alpha(x) for x in e["sigma_alpha_exps"]]
+    assert cnt == 3 and nums.tolist() == [b.alpha(x) for x in e["numbers_alpha_exps"]]
+
+
+def test_exhaustive_one_and_two_bit_errors_32_8():
+    """lib/qa_bch.cc:539-604: shortened (32, 8) code over GF(2^6), t = 4."""
+    b = T.OracleBch(6, 0b1000011, 4, 32)
+    assert (b.n, b.k) == (32, 8)
+    msg = np.array([[0xA7]], np.uint8)
+    cw = b.encode_bytes(msg)[0]
+    for i in range(32):
+        for j in range(i, 32):
+            pos = [i] if i == j else [i, j]
+            out, ret = b.decode_bytes(T.flip_bits(cw, pos)[None])
+            assert ret[0] == len(pos) and out[0, 0] == 0xA7
+
+
+def test_all_dvbs2_codes_correct_t_errors():
+    """lib/qa_bch.cc:652-747: every (n, t) of the parameter table: encode, t random errors, decode."""
+    rows = json.load(open(os.path.join(GOLD, "fec_params.json")))["rows"]
+    seen = set()
+    rng = np.random.default_rng(11)
+    for r in rows:
+        key = (r["framesize_id"], r["bch_n"], r["bch_t"])
+        if key in seen or r["bch_n"] % 8 or r["bch_k"] % 8:
+            continue
+        seen.add(key)
+        m, prim = T.BCH_FIELDS[r["framesize_id"]]
+        b = T.OracleBch(m, prim, r["bch_t"], r["bch_n"])
+        assert b.k == r["bch_k"], r
+        msg = rng.integers(0, 256, (1, b.k // 8), dtype=np.uint8)
+        cw = b.encode_bytes(msg)
+        pos = rng.choice(b.n, r["bch_t"], replace=False)
+        out, ret = b.decode_bytes(T.flip_bits(cw[0], pos)[None])
+        assert ret[0] == r["bch_t"] and np.array_equal(out, msg)
+    assert len(seen) >= 40
+
+
+def test_beyond_t_returns_failure():
+    """lib/qa_bch.cc:606-650: more than t errors -> -1 (or the exception path, reported as -2)."""
+    b = T.OracleBch(14, 0b100000000101011, 12, 3240)
+    rng = np.random.default_rng(5)
+    msg = rng.integers(0, 256, (1, b.k // 8), dtype=np.uint8)
+    cw = b.encode_bytes(msg)[0]
+    rets = []
+    for trial in range(30):
+        pos = rng.choice(b.n, 13 + trial, replace=False)
+        rets.append(int(b.decode_bytes(T.flip_bits(cw, pos)[None])[1][0]))
+    assert all(r in (-1, -2) for r in rets)
+
+
+# ------------------------------------------------------------------ demapper (lib/qa_qpsk.cc:67-79)
+def test_qpsk_soft_demap_kat():
+    k = json.load(open(os.path.join(GOLD, "demap_kat.json")))
+    syms = np.array([complex(a, b) for a, b in k["syms"]], np.complex64)[None]
+    out = T.oracle_demap(syms, np.float32(2 * np.sqrt(2)), 4)
+    assert out[0].tolist() == k["expected"]
+
+
+# ------------------------------------------------------------------ LDPC golden digests (from the genuine reference)
+LG = json.load(open(os.path.join(GOLD, "ldpc_golden.json")))
+
+
+@pytest.mark.parametrize("case", LG, ids=lambda c: f"{c['table']}-{c['kind']}")
+def test_ldpc_oracle_matches_reference_digests(case):
+    x = T.make_input(case["table"], case["kind"], case["n_frames"], **case["params"])
+    assert T.sha(x) == case["input_sha256"], "input generator drifted"
+    N = x.shape[1]
+    for G in ("32", "16"):
+        y, ret = T.oracle_ldpc_decode(case["table"], x, int(G), case["trials"])
+        want = case["results"][G]
+        assert ret == want["ret"]
+        assert T.sha(y) == want["llr_sha256"]
+        assert T.sha(T.pack_bits(y, N)) == want["bits_sha256"]
+
+
+def test_ldpc_oracle_vs_reference_live():
+    """Only where oracle/_ref exists (it is built in the container that has /root/reference and travels as a .so)."""
+    if T.ref_ldpc() is None:
+        pytest.skip("oracle/_ref not built")
+    x = T.make_input("S2_TABLE_C3", "awgn", 32, seed=21, amp=5, sigma=5.5)
+    a, ra = T.oracle_ldpc_decode("S2_TABLE_C3", x, 32, 20)
+    b, rb = T.ref_ldpc_decode("S2_TABLE_C3", x, 0, 20)
+    assert ra == rb and np.array_equal(a, b)
+
+
+# ------------------------------------------------------------------ product host logic (no device needed)
+def test_fec_params_match_reference():
+    """gr-dvbs2rx_amd's parameter map vs the reference's get_fec_info() + table switch (tests/golden/fec_params.json)."""
+    g = json.load(open(os.path.join(GOLD, "fec_params.json")))
+    assert capi.lib.dvbs2_rate_name(3) == b"C1_2" and capi.lib.dvbs2_rate_from_name(b"C9_10") == g["rates"].index("C9_10")
+    for r in g["rows"]:
+        fi = get_fec_info(r["standard_id"], r["framesize_id"], r["rate_id"])
+        assert (fi["bch_k"], fi["bch_n"], fi["bch_t"], fi["ldpc_k"], fi["ldpc_n"], fi["table"]) == \
+               (r["bch_k"], r["bch_n"], r["bch_t"], r["ldpc_k"], r["ldpc_n"], r["table"]), r
+    have = {(r["standard_id"], r["framesize_id"], r["rate_id"]) for r in g["rows"]}
+    fi = capi.FecInfo()
+    for s in range(2):
+        for f in range(3):
+            for rate in range(len(g["rates"])):
+                rc = capi.lib.dvbs2_get_fec_info(s, f, rate, fi)
+                assert (rc == 0) == ((s, f, rate) in have)
+
+
+def test_c_abi_exports_every_declared_symbol():
+    hdr = open(os.path.join(T.ROOT, "include", "dvbs2_fec_hip.h")).read()
+    declared = set(re.findall(r"\b(dvbs2_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {n for n in declared if n.endswith("_t")}
+    assert declared == set(capi.SYMBOLS), declared ^ set(capi.SYMBOLS)
+    for name in declared:
+        assert getattr(capi.lib, name) is not None
+
+
+def test_create_fails_loudly_without_device_or_with_bad_args():
+    h = C.c_void_p()
+    if capi.lib.dvbs2_device_count() == 0:
+        assert capi.lib.dvbs2_ldpc_create(C.byref(h), 0, 1, 3, 32, 8, 0) == capi.EDEVICE
+        assert b"no HIP device" in capi.lib.dvbs2_last_error()
+        assert capi.lib.dvbs2_bch_create(C.byref(h), 0, 1, 3, 8, 0) == capi.EDEVICE
+        assert capi.lib.dvbs2_demap_create(C.byref(h), 1, 3, 0, 8, 0) == capi.EDEVICE
+    assert capi.lib.dvbs2_ldpc_create(C.byref(h), 0, 1, 50, 32, 8, 0) == capi.EINVAL  # C_OTHER
+    assert capi.lib.dvbs2_ldpc_create_table(C.byref(h), b"NOPE", 8, 1, 1, 0) == capi.EINVAL
