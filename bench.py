@@ -82,14 +82,9 @@ def main():
 
     import numpy as np
     import torch
-    import torch.distributed as dist
-    from dvbs2rx_amd import LdpcDecoder, capi, ldpc_table_info
+    from dvbs2rx_amd import LdpcDecoder, capi, ldpc_table_info, shard
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+    world, rank, local = shard.init_from_env()  # nccl (= RCCL) rendezvous when WORLD_SIZE > 1
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -121,10 +116,7 @@ def main():
     def step():
         dec.work_device(llr.data_ptr(), nf, d_bits.data_ptr(), 0, d_ret.data_ptr(), stream)
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+    barrier = shard.barrier_sync
 
     # parity gate on the first group (rank 0): GPU output must equal the CPU checker bit for bit
     parity = "skipped"
@@ -159,10 +151,7 @@ def main():
     kern_ms, launches = dec.profile(False)
     iters_mean = float((args.trials - d_ret.clamp(min=0)).float().mean().item()) if args.input != "noise" else float(args.trials)
 
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
+    dt = shard.max_over_ranks(dt, device=dev)
 
     if rank == 0:
         frames_total = world * nf * args.steps
@@ -190,8 +179,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(table, N, args.trials)
         print(json.dumps(out))
-    if world > 1:
-        dist.destroy_process_group()
+    shard.finalize()
 
 
 if __name__ == "__main__":

@@ -1,0 +1,227 @@
+// dvbs2rx_hip_blocks.h -- host-side mirror (C++17, header only) of the three reference blocks on the FEC hot
+// path, implemented over the C ABI of libdvbs2_fec_hip.so. Same class names, make() argument order and
+// meaning, forecast()/general_work() item accounting, getters and error behaviour as the reference:
+//
+//   gr::dvbs2rx::ldpc_decoder_bb        include/gnuradio/dvbs2rx/ldpc_decoder_bb.h:37-50, lib/ldpc_decoder_bb_impl.cc
+//   gr::dvbs2rx::bch_decoder_bb         include/gnuradio/dvbs2rx/bch_decoder_bb.h,        lib/bch_decoder_bb_impl.cc
+//   gr::dvbs2rx::xfecframe_demapper_cb  include/gnuradio/dvbs2rx/xfecframe_demapper_cb.h, lib/xfecframe_demapper_cb_impl.cc
+//
+// It deliberately does NOT depend on GNU Radio (absent from the build image): the classes expose the
+// gr::block work-function signature with plain std::vector arguments, so that the reference's *_impl classes can
+// either derive from these or forward to them (INTEGRATION.md shows the two-line patch). What GNU Radio itself
+// provides (scheduler, buffers, message ports) stays in the reference; the llr_pdu hand-off is a callback here.
+#pragma once
+#include <cstdint>
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <functional>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/dvbs2_fec_hip.h"
+
+namespace dvbs2rx_hip {
+
+// enumerations with the reference's values (dvb_config.h)
+enum dvb_standard_t { STANDARD_DVBS2 = 0, STANDARD_DVBT2 };
+enum dvb_framesize_t { FECFRAME_SHORT = 0, FECFRAME_NORMAL, FECFRAME_MEDIUM };
+enum dvb_constellation_t { MOD_QPSK = 0, MOD_16QAM, MOD_8PSK = 2 };
+enum dvb_outputmode_t { OM_CODEWORD = 0, OM_MESSAGE };
+enum dvb_infomode_t { INFO_OFF = 0, INFO_ON };
+typedef int dvb_code_rate_t; // use dvbs2_rate_from_name("C1_2") or the reference's enumerator value
+
+typedef std::vector<int> gr_vector_int;
+typedef std::vector<const void*> gr_vector_const_void_star;
+typedef std::vector<void*> gr_vector_void_star;
+
+inline void check(int rc)
+{
+    if (rc != DVBS2_OK) throw std::runtime_error(dvbs2_last_error());
+}
+
+// ---------------------------------------------------------------------------------------------- LDPC
+class ldpc_decoder_bb {
+public:
+    typedef std::shared_ptr<ldpc_decoder_bb> sptr;
+    // batch_frames replaces the reference's d_simd_size as the scheduling granule: general_work consumes whole
+    // multiples of it; group_size keeps the reference's batch-coupled stopping rule (32 = AVX2, 16 otherwise).
+    static sptr make(dvb_standard_t standard, dvb_framesize_t framesize, dvb_code_rate_t rate,
+                     dvb_constellation_t /*constellation*/, dvb_outputmode_t outputmode, dvb_infomode_t /*infomode*/,
+                     int max_trials, int /*debug_level*/ = 0, int group_size = 32, int batch_frames = 512, int device = 0)
+    {
+        return sptr(new ldpc_decoder_bb(standard, framesize, rate, outputmode, max_trials, group_size, batch_frames, device));
+    }
+    ~ldpc_decoder_bb() { dvbs2_ldpc_destroy(d_h); }
+
+    // lib/ldpc_decoder_bb_impl.cc:380-389
+    void forecast(int noutput_items, gr_vector_int& ninput_items_required) const
+    {
+        if (d_output_mode == OM_MESSAGE) ninput_items_required[0] = (noutput_items / (int)d_kldpc_bytes) * (int)d_nldpc;
+        else ninput_items_required[0] = 8 * noutput_items;
+    }
+    int output_multiple() const { return (int)((d_output_mode ? d_kldpc_bytes : d_nldpc_bytes) * (unsigned)d_group); }
+
+    // lib/ldpc_decoder_bb_impl.cc:394-455. Returns the items produced; *consumed gets consume_each()'s argument.
+    int general_work(int noutput_items, gr_vector_int& /*ninput_items*/, gr_vector_const_void_star& input_items,
+                     gr_vector_void_star& output_items, int* consumed)
+    {
+        const int8_t* in = static_cast<const int8_t*>(input_items[0]);
+        unsigned char* out = static_cast<unsigned char*>(output_items[0]);
+        const int trials = d_max_trials == 0 ? 25 : d_max_trials; // DEFAULT_TRIALS, :391,402
+        const int output_size = (int)(d_output_mode ? d_kldpc_bytes : d_nldpc_bytes);
+        int n_frames = noutput_items / output_size;
+        n_frames -= n_frames % d_group;
+        int done = 0;
+        while (done < n_frames) {
+            const int nf = std::min(n_frames - done, d_batch);
+            const int ng = nf / d_group;
+            d_ret.resize(ng);
+            int8_t* llr_out = nullptr;
+            if (d_llr_pdu) { d_soft.resize((size_t)nf * d_nldpc); llr_out = d_soft.data(); }
+            check(dvbs2_ldpc_decode(d_h, in + (size_t)done * d_nldpc, nf, trials, d_output_mode, out + (size_t)done * output_size,
+                                    llr_out, d_ret.data()));
+            for (int g = 0; g < ng; g++) { // :411-419
+                d_total_trials += d_ret[g] < 0 ? trials : trials - d_ret[g];
+                if (d_llr_pdu) d_llr_pdu(d_frame_cnt, d_group, llr_out + (size_t)g * d_group * d_nldpc, (size_t)d_group * d_nldpc); // :422-429
+                d_frame_cnt += d_group;
+                d_batch_cnt++;
+            }
+            done += nf;
+        }
+        *consumed = n_frames * (int)d_nldpc;
+        return n_frames * output_size;
+    }
+    unsigned int get_average_trials() const { return d_batch_cnt ? (unsigned)(d_total_trials / d_batch_cnt) : 0; } // .h:63
+    // the llr_pdu message port: (frame_cnt, simd_size, decoded LLRs, count)
+    void set_llr_pdu_handler(std::function<void(uint64_t, int, const int8_t*, size_t)> f) { d_llr_pdu = std::move(f); }
+
+private:
+    ldpc_decoder_bb(dvb_standard_t standard, dvb_framesize_t framesize, dvb_code_rate_t rate, dvb_outputmode_t outputmode,
+                    int max_trials, int group_size, int batch_frames, int device)
+        : d_output_mode(outputmode), d_max_trials(max_trials), d_group(group_size), d_batch(batch_frames - batch_frames % group_size)
+    {
+        if (d_batch < d_group) d_batch = d_group;
+        dvbs2_fec_info_t fi;
+        check(dvbs2_get_fec_info(standard, framesize, rate, &fi));
+        d_kldpc = fi.ldpc_k; d_nldpc = fi.ldpc_n; d_kldpc_bytes = d_kldpc / 8; d_nldpc_bytes = d_nldpc / 8;
+        check(dvbs2_ldpc_create(&d_h, standard, framesize, rate, group_size, d_batch, device));
+    }
+    dvbs2_ldpc_t* d_h = nullptr;
+    unsigned d_nldpc = 0, d_nldpc_bytes = 0, d_kldpc = 0, d_kldpc_bytes = 0;
+    int d_output_mode, d_max_trials, d_group, d_batch;
+    uint64_t d_frame_cnt = 0, d_batch_cnt = 0, d_total_trials = 0;
+    std::vector<int32_t> d_ret;
+    std::vector<int8_t> d_soft;
+    std::function<void(uint64_t, int, const int8_t*, size_t)> d_llr_pdu;
+};
+
+// ---------------------------------------------------------------------------------------------- BCH
+class bch_decoder_bb {
+public:
+    typedef std::shared_ptr<bch_decoder_bb> sptr;
+    static sptr make(dvb_standard_t standard, dvb_framesize_t framesize, dvb_code_rate_t rate, dvb_outputmode_t /*outputmode*/,
+                     int /*debug_level*/ = 0, int batch_frames = 512, int device = 0)
+    {
+        return sptr(new bch_decoder_bb(standard, framesize, rate, batch_frames, device));
+    }
+    ~bch_decoder_bb() { dvbs2_bch_destroy(d_h); }
+    void forecast(int noutput_items, gr_vector_int& req) const { req[0] = (noutput_items / d_k_bytes) * d_n_bytes; } // :78-82
+    int output_multiple() const { return d_k_bytes; }
+    // lib/bch_decoder_bb_impl.cc:84-117. A codeword on which the reference would have thrown (status -2) throws here too.
+    int general_work(int noutput_items, gr_vector_int&, gr_vector_const_void_star& input_items, gr_vector_void_star& output_items,
+                     int* consumed)
+    {
+        const unsigned char* in = static_cast<const unsigned char*>(input_items[0]);
+        unsigned char* out = static_cast<unsigned char*>(output_items[0]);
+        const int n_codewords = noutput_items / d_k_bytes;
+        int done = 0;
+        while (done < n_codewords) {
+            const int nf = std::min(n_codewords - done, d_batch);
+            d_corr.resize(nf);
+            check(dvbs2_bch_decode(d_h, in + (size_t)done * d_n_bytes, nf, out + (size_t)done * d_k_bytes, d_corr.data()));
+            for (int i = 0; i < nf; i++) {
+                if (d_corr[i] == -2) throw std::runtime_error("BCH decoder: the reference throws on this codeword (see dvbs2_fec_hip.h)");
+                if (d_corr[i] == -1) d_frame_error_cnt++;
+                d_frame_cnt++;
+            }
+            done += nf;
+        }
+        *consumed = n_codewords * d_n_bytes;
+        return n_codewords * d_k_bytes;
+    }
+    uint64_t get_frame_count() const { return d_frame_cnt; }       // lib/bch_decoder_bb_impl.h:46
+    uint64_t get_error_count() const { return d_frame_error_cnt; } // :47
+
+private:
+    bch_decoder_bb(dvb_standard_t standard, dvb_framesize_t framesize, dvb_code_rate_t rate, int batch_frames, int device) : d_batch(batch_frames)
+    {
+        check(dvbs2_bch_create(&d_h, standard, framesize, rate, batch_frames, device));
+        int n, k, t;
+        check(dvbs2_bch_params(d_h, &n, &k, &t));
+        d_n_bytes = n / 8; d_k_bytes = k / 8;
+    }
+    dvbs2_bch_t* d_h = nullptr;
+    int d_n_bytes = 0, d_k_bytes = 0, d_batch;
+    uint64_t d_frame_cnt = 0, d_frame_error_cnt = 0;
+    std::vector<int32_t> d_corr;
+};
+
+// ---------------------------------------------------------------------------------------------- demapper
+class xfecframe_demapper_cb {
+public:
+    typedef std::shared_ptr<xfecframe_demapper_cb> sptr;
+    static sptr make(dvb_framesize_t framesize, dvb_code_rate_t rate, dvb_constellation_t constellation, int batch_frames = 512, int device = 0)
+    {
+        return sptr(new xfecframe_demapper_cb(framesize, rate, constellation, batch_frames, device));
+    }
+    ~xfecframe_demapper_cb() { dvbs2_demap_destroy(d_h); }
+    void forecast(int noutput_items, gr_vector_int& req) const { req[0] = noutput_items / d_n_mod; } // :95-99
+    int output_multiple() const { return d_fecframe_len; }
+    // lib/xfecframe_demapper_cb_impl.cc:101-186. Until the first refined estimate arrives (set_snr / the llr_pdu
+    // path of the reference), N0 comes from the pre-decoder estimate of each frame, like d_waiting_first_llr.
+    int general_work(int noutput_items, gr_vector_int&, gr_vector_const_void_star& input_items, gr_vector_void_star& output_items, int* consumed)
+    {
+        const float* in = static_cast<const float*>(input_items[0]); // gr_complex = 2 floats
+        int8_t* out = static_cast<int8_t*>(output_items[0]);
+        const int n_frames = noutput_items / d_fecframe_len;
+        int done = 0;
+        while (done < n_frames) {
+            const int nf = std::min(n_frames - done, d_batch);
+            const float* p = in + (size_t)done * d_xfecframe_len * 2;
+            if (d_waiting_first_llr) {
+                d_n0.resize(nf);
+                check(dvbs2_demap_estimate_snr(d_h, p, nf, d_n0.data()));
+                for (int i = 0; i < nf; i++) { d_snr_lin = d_n0[i]; d_n0[i] = 1.0f / d_n0[i]; } // N0 = Es / snr, Es = 1
+                check(dvbs2_demap_soft(d_h, p, nf, d_n0.data(), nf, out + (size_t)done * d_fecframe_len));
+            } else {
+                const float n0 = 1.0f / d_snr_lin;
+                check(dvbs2_demap_soft(d_h, p, nf, &n0, 1, out + (size_t)done * d_fecframe_len));
+            }
+            done += nf; d_frame_cnt += nf;
+        }
+        *consumed = n_frames * d_xfecframe_len;
+        return n_frames * d_fecframe_len;
+    }
+    float get_snr() const { return 10.0f * std::log10(d_snr_lin); } // lib/xfecframe_demapper_cb_impl.h:74
+    // refined (post-decoder) linear SNR, the result of the reference's handle_llr_pdu() (:188-318)
+    void set_snr_lin(float snr_lin) { d_snr_lin = snr_lin; d_waiting_first_llr = false; }
+
+private:
+    xfecframe_demapper_cb(dvb_framesize_t framesize, dvb_code_rate_t rate, dvb_constellation_t constellation, int batch_frames, int device) : d_batch(batch_frames)
+    {
+        check(dvbs2_demap_create(&d_h, framesize, rate, constellation, batch_frames, device)); // throws "Unsupported constellation"
+        int order;
+        check(dvbs2_demap_params(d_h, &d_xfecframe_len, &d_fecframe_len, &d_n_mod, &order));
+    }
+    dvbs2_demap_t* d_h = nullptr;
+    int d_xfecframe_len = 0, d_fecframe_len = 0, d_n_mod = 0, d_batch;
+    bool d_waiting_first_llr = true;
+    float d_snr_lin = 1.0f;
+    uint64_t d_frame_cnt = 0;
+    std::vector<float> d_n0;
+};
+
+} // namespace dvbs2rx_hip

@@ -1,0 +1,57 @@
+"""Frame sharding across the GPUs of one node: FECFRAME groups are independent, so the batch is
+split into contiguous, G-aligned ranges -- one process per GPU, NO data-path collective. torch.distributed is
+only used for the launch rendezvous, the timing barrier and the max-over-ranks reduction of the elapsed time."""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def shard_range(total_frames, world, rank, group_size):
+    """Contiguous [start, stop) of rank's frames; every boundary is a multiple of group_size so that the
+    reference's batch grouping (frames [G*g, G*g+G) share an iteration count) is preserved."""
+    n_groups = (total_frames + group_size - 1) // group_size
+    g0 = (n_groups * rank) // world
+    g1 = (n_groups * (rank + 1)) // world
+    return min(g0 * group_size, total_frames), min(g1 * group_size, total_frames)
+
+
+def init_from_env(backend=None):
+    """Returns (world, rank, local_rank). Initialises the default process group when WORLD_SIZE > 1."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        kw = {}
+        if backend == "nccl":
+            kw["device_id"] = torch.device("cuda", local)
+        dist.init_process_group(backend=backend, **kw)
+    return world, rank, local
+
+
+def barrier_sync():
+    if dist.is_initialized():
+        dist.barrier()
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+
+
+def max_over_ranks(value, device=None):
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    if dist.is_initialized():
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def sum_over_ranks(value, device=None):
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    if dist.is_initialized():
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t.item())
+
+
+def finalize():
+    if dist.is_initialized():
+        dist.destroy_process_group()
