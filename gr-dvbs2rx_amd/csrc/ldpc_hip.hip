@@ -36,7 +36,7 @@ constexpr int kHalf = 384;          // threads per frame (6 wavefronts; threads 
 constexpr int kThreads = 2 * kHalf; // 12 wavefronts
 constexpr int kM = 360;
 constexpr int kMsgStride = 384;     // message slots per (layer, word)
-constexpr int kSvWords = 13;        // sign-vector dwords per 360-bit group (360 bits + 32-bit wrap extension)
+constexpr int kSvWords = 14;        // sign-vector dwords per 360-bit group (360 bits + 32-bit wrap extension, even for b64 stores)
 
 // Layer record (uniform data, read with scalar loads): RS = 2*DMAX + 4 dwords.
 //   word 0: cnt | sync_before << 15 | block << 16
@@ -58,8 +58,10 @@ __device__ __forceinline__ void check_node(uint8_t* __restrict__ lds, const uint
     int ad[DEG], Lb[DEG];
 #pragma unroll
     for (int k = 0; k < DEG; k++) {
-        const int t0 = jj + (int)ent[2 * k];
-        ad[k] = (uint32_t)jj < ent[2 * k + 1] ? t0 : t0 - kM;
+        // address = S0 + jj, minus 360 when jj >= thr; the two parity entries have rot = 0 (never wrap) except
+        // the previous-parity entry of layer 0 (rot = 359)
+        if (k >= DEG - 2 && !(LAYER0 && k == DEG - 1)) ad[k] = jj + (int)ent[2 * k];
+        else ad[k] = jj + (int)ent[2 * k] - ((uint32_t)jj < ent[2 * k + 1] ? 0 : kM);
     }
 #pragma unroll
     for (int k = 0; k < DEG; k++) Lb[k] = lds[ad[k]];
@@ -84,10 +86,12 @@ __device__ __forceinline__ void check_node(uint8_t* __restrict__ lds, const uint
     }
 #pragma unroll
     for (int w = 0; w < (DEG + 3) / 4; w++) nm[w] = 0;
+    const int s01 = min0 + min1;
 #pragma unroll
     for (int k = 0; k < DEG; k++) {
-        // R5 out = vsign(mag == min0 ? min1 : min0, (signs ^ x) | 127)
-        const int other = (mg[k] == min0) ? min1 : min0;
+        // R5 out = vsign(mag == min0 ? min1 : min0, (signs ^ x) | 127); mag is min0 or >= min1, so the selected
+        // magnitude is min0 + min1 - min(mag, min1)
+        const int other = s01 - min(mg[k], min1);
         const int sg = (signs ^ inp[k]) >> 31;
         const int out = (other ^ sg) - sg;
         // R6 LLR = sat8(inp + out) with the unclamped out; R7 stored message = clamp(out, -32, 31)
@@ -95,6 +99,96 @@ __device__ __forceinline__ void check_node(uint8_t* __restrict__ lds, const uint
         if (!(LAYER0 && k == DEG - 1) || last_valid) lds[ad[k]] = (uint8_t)nl;
         const int nmsg = min(max(out, -32), 31) + 128;
         nm[k >> 2] |= (uint32_t)nmsg << (8 * (k & 3));
+    }
+}
+
+// Hazard layer (two or more entries of one group, ldpc_schedule.h): the reference's strictly ordered update
+// makes check j see what checks j' < j wrote to the bits they share. Only the NC hazard entries (placed first)
+// carry that dependency, so the check node is split in three:
+//   P1  all 360 rows in parallel: regular entries are read and reduced to a partial (min0, min1, signs);
+//   P2  ascending blocks of B_i rows, one workgroup barrier per block: the rows of the block read their
+//       hazard bits (now final with respect to all earlier rows), complete (min0, min1, signs), and write the
+//       hazard bits back;
+//   P3  all rows in parallel: outputs of the regular entries.
+// The result is identical to the sequential order: inside a block no two rows share a bit, blocks ascend, and
+// a regular entry's bits are touched by exactly one row of the layer.
+// NC (2, 4 or 8) is the number of entries handled in P2: the hazard entries, rounded up with regular data entries
+// (moving a regular entry into the ordered part does not change the result).
+constexpr int kMaxHazard = 8;
+constexpr int kHazardWalk = 15; // header code: too many hazard entries, fall back to the single-wave chunk walk
+template <int DEG, int NC, bool LAYER0>
+__device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, const uint32_t* ent, int jj, bool work,
+                                                  int block, const uint32_t* mw, uint32_t* nm)
+{
+    int ad[DEG], inp[DEG], mg[DEG];
+    int min0 = 127, min1 = 127, signs = 0;
+    const bool last_valid = !LAYER0 || jj != 0;
+    if (work) {
+#pragma unroll
+        for (int k = 0; k < DEG; k++) {
+            if (k >= DEG - 2 && !(LAYER0 && k == DEG - 1)) ad[k] = jj + (int)ent[2 * k];
+            else ad[k] = jj + (int)ent[2 * k] - ((uint32_t)jj < ent[2 * k + 1] ? 0 : kM);
+        }
+#pragma unroll
+        for (int k = 0; k < DEG; k++) {
+            if (k >= NC) { // regular entry
+                const int Lb = lds[ad[k]];
+                const int mb = (int)((mw[k >> 2] >> (8 * (k & 3))) & 0xffu);
+                int d = min(max(Lb - mb, -128), 127);
+                int mag = (int)__builtin_amdgcn_sad_u16((uint32_t)Lb, (uint32_t)mb, 0xffffffffu);
+                mag = min(max(mag, 0), 126);
+                if (LAYER0 && k == DEG - 1) { d = last_valid ? d : 0; mag = last_valid ? mag : 127; }
+                inp[k] = d; mg[k] = mag;
+                min1 = min(max(mag, min0), min1);
+                min0 = min(min0, mag);
+                signs ^= d;
+            }
+        }
+    }
+#pragma unroll
+    for (int w = 0; w < (DEG + 3) / 4; w++) nm[w] = 0;
+    for (int start = 0; start < kM; start += block) {
+        if (work && jj >= start && jj < start + block) {
+            int Lh[NC];
+#pragma unroll
+            for (int k = 0; k < NC; k++) Lh[k] = lds[ad[k]];
+#pragma unroll
+            for (int k = 0; k < NC; k++) {
+                const int mb = (int)((mw[k >> 2] >> (8 * (k & 3))) & 0xffu);
+                const int d = min(max(Lh[k] - mb, -128), 127);
+                int mag = (int)__builtin_amdgcn_sad_u16((uint32_t)Lh[k], (uint32_t)mb, 0xffffffffu);
+                mag = min(max(mag, 0), 126);
+                inp[k] = d; mg[k] = mag;
+                min1 = min(max(mag, min0), min1);
+                min0 = min(min0, mag);
+                signs ^= d;
+            }
+#pragma unroll
+            for (int k = 0; k < NC; k++) {
+                const int other = (mg[k] == min0) ? min1 : min0;
+                const int sg = (signs ^ inp[k]) >> 31;
+                const int out = (other ^ sg) - sg;
+                lds[ad[k]] = (uint8_t)min(max(inp[k] + out + 128, 0), 255);
+                nm[k >> 2] |= (uint32_t)(min(max(out, -32), 31) + 128) << (8 * (k & 3));
+            }
+        }
+        // the next block reads what this one wrote: a workgroup barrier, unless both blocks sit inside one and the
+        // same wavefront (LDS operations of a wave execute in program order)
+        if ((start >> 6) != ((start + 2 * block - 1) >> 6)) __syncthreads();
+    }
+    __syncthreads();
+    if (work) {
+#pragma unroll
+        for (int k = 0; k < DEG; k++) {
+            if (k >= NC) {
+                const int other = (mg[k] == min0) ? min1 : min0;
+                const int sg = (signs ^ inp[k]) >> 31;
+                const int out = (other ^ sg) - sg;
+                const int nl = min(max(inp[k] + out + 128, 0), 255);
+                if (!(LAYER0 && k == DEG - 1) || last_valid) lds[ad[k]] = (uint8_t)nl;
+                nm[k >> 2] |= (uint32_t)(min(max(out, -32), 31) + 128) << (8 * (k & 3));
+            }
+        }
     }
 }
 
@@ -109,20 +203,32 @@ __device__ __forceinline__ void check_node(uint8_t* __restrict__ lds, const uint
         DVBS2_DEG_CASE(27) DVBS2_DEG_CASE(28) DVBS2_DEG_CASE(29) DVBS2_DEG_CASE(30) DVBS2_DEG_CASE(31) DVBS2_DEG_CASE(32) \
         default: break; }
 
+#define DVBS2_HAZ_CALL(D, NCV) { if constexpr (D - 2 >= NCV) { \
+        if (layer0) check_node_hazard<D, NCV, true>(lds, ent, jj, work, block, mw, nm); else check_node_hazard<D, NCV, false>(lds, ent, jj, work, block, mw, nm); } }
+#define DVBS2_HAZ_CASE(D) case D: if constexpr (D >= 4 && D <= DMAX && D > DMAX - 8) { \
+        if (nc == 2) DVBS2_HAZ_CALL((D >= 4 ? D : 4), 2) else if (nc == 4) DVBS2_HAZ_CALL((D >= 4 ? D : 4), 4) else DVBS2_HAZ_CALL((D >= 4 ? D : 4), 8) } break;
+#define DVBS2_HAZ_SWITCH switch (deg) { \
+        DVBS2_HAZ_CASE(4) DVBS2_HAZ_CASE(5) DVBS2_HAZ_CASE(6) DVBS2_HAZ_CASE(7) DVBS2_HAZ_CASE(8) \
+        DVBS2_HAZ_CASE(9) DVBS2_HAZ_CASE(10) DVBS2_HAZ_CASE(11) DVBS2_HAZ_CASE(12) DVBS2_HAZ_CASE(13) DVBS2_HAZ_CASE(14) \
+        DVBS2_HAZ_CASE(15) DVBS2_HAZ_CASE(16) DVBS2_HAZ_CASE(17) DVBS2_HAZ_CASE(18) DVBS2_HAZ_CASE(19) DVBS2_HAZ_CASE(20) \
+        DVBS2_HAZ_CASE(21) DVBS2_HAZ_CASE(22) DVBS2_HAZ_CASE(23) DVBS2_HAZ_CASE(24) DVBS2_HAZ_CASE(25) DVBS2_HAZ_CASE(26) \
+        DVBS2_HAZ_CASE(27) DVBS2_HAZ_CASE(28) DVBS2_HAZ_CASE(29) DVBS2_HAZ_CASE(30) DVBS2_HAZ_CASE(31) DVBS2_HAZ_CASE(32) \
+        default: break; }
+
 template <int DMAX, bool TIMING>
 __global__ __launch_bounds__(kThreads) void ldpc_layered_kernel(
     const uint32_t* __restrict__ recs, const int8_t* __restrict__ llr_in, uint8_t* __restrict__ state,
     uint32_t* __restrict__ msgs, int* __restrict__ iters, int* __restrict__ good, const int* __restrict__ target,
     int n_frames, int N, int K, int q, int cap, int stop_on_good, unsigned long long* __restrict__ tdbg)
 {
-    unsigned long long tm_bar = 0, tm_body = 0, tm_conf = 0, tm_synd = 0, tm_sweep = 0, tm_load = 0;
+    unsigned long long tm_bar = 0, tm_body = 0, tm_conf = 0, tm_synd = 0, tm_sweep = 0, tm_load = 0, tm_s1 = 0;
 #define TSTAMP(x) do { if (TIMING) { x = __builtin_readcyclecounter(); } } while (0)
     unsigned long long tA = 0, tB = 0, tC = 0, tS0 = 0, tS1 = 0;
     TSTAMP(tA);
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_all[];
     constexpr int RS = rec_stride(DMAX);
     constexpr int MW = DMAX / 4; // message dwords per check (fixed per kernel variant)
-    const int half = threadIdx.x >= kHalf ? 1 : 0; // wave-uniform
+    const int half = __builtin_amdgcn_readfirstlane(threadIdx.x >= kHalf ? 1 : 0); // wave-uniform, and the compiler knows it
     const int tid = threadIdx.x - half * kHalf;
     uint8_t* lds = lds_all + half * half_lds_bytes(N);
     uint32_t* sv = reinterpret_cast<uint32_t*>(lds + N); // N % 8 == 0
@@ -180,16 +286,22 @@ __global__ __launch_bounds__(kThreads) void ldpc_layered_kernel(
         // LLR or an odd number of negative LLRs. Barriers are taken by every thread; work only by halves that need it.
         const bool need_synd = !finished && (stop_on_good || it >= tgt);
         if (need_synd) {
-            // Step 1: 360-bit sign vector per group via wave ballots.
+            // Step 1: 360-bit sign vector per group via wave ballots (4 groups per trip to batch the LDS reads).
             unsigned long long zero_any = 0;
-            for (int g = 0; g < NG; g++) {
-                const uint32_t v = active ? lds[kM * g + tid] : 0xffu;
-                const unsigned long long neg = __ballot(v < 0x80u);
-                zero_any |= __ballot(v == 0x80u);
-                if (lane == 0) { sv[g * kSvWords + 2 * wave] = (uint32_t)neg; sv[g * kSvWords + 2 * wave + 1] = (uint32_t)(neg >> 32); }
+            for (int g0 = 0; g0 < NG; g0 += 4) {
+                uint32_t v[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) v[u] = (active && g0 + u < NG) ? lds[kM * (g0 + u) + tid] : 0xffu;
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const unsigned long long neg = __ballot(v[u] < 0x80u);
+                    zero_any |= __ballot(v[u] == 0x80u);
+                    if (lane == 0 && g0 + u < NG) *reinterpret_cast<uint2*>(&sv[(g0 + u) * kSvWords + 2 * wave]) = make_uint2((uint32_t)neg, (uint32_t)(neg >> 32));
+                }
             }
             if (zero_any != 0 && lane == 0) flags[0] = 1;
         }
+        TSTAMP(tC); tm_s1 += tC - tS0;
         __syncthreads();
         if (need_synd && tid < NG) { // wrap extension: bits 360+u = bit u
             uint32_t* p = sv + tid * kSvWords;
@@ -204,17 +316,22 @@ __global__ __launch_bounds__(kThreads) void ldpc_layered_kernel(
             for (int item = tid; item < q * 12; item += kHalf) {
                 const int i = item / 12, w = item - 12 * i;
                 const uint32_t* rec = recs + (size_t)i * RS;
-                const int deg = (int)(rec[0] & 0x7fffu) + 2;
+                const int deg = (int)(rec[0] & 0xffu) + 2;
+                uint32_t e0[DMAX], e1[DMAX];
+#pragma unroll
+                for (int k = 0; k < DMAX; k++) { e0[k] = rec[4 + 2 * k]; e1[k] = rec[5 + 2 * k]; } // padded records: always readable
                 uint32_t acc = 0;
-                for (int k = 0; k < deg; k++) {
-                    const int S0 = (int)rec[4 + 2 * k], thr = (int)rec[5 + 2 * k];
-                    const int rot = kM - thr;          // S0 = 360*g + rot
-                    const int g360 = S0 - rot;
-                    const int t0 = wrap360(32 * w + rot);
-                    const uint32_t* p = sv + (g360 / kM) * kSvWords + (t0 >> 5);
-                    uint32_t x = __funnelshift_r(p[0], p[1], t0 & 31);
-                    if (i == 0 && k == deg - 1 && w == 0) x &= ~1u; // check (0,0): no previous parity
-                    acc ^= x;
+#pragma unroll
+                for (int k = 0; k < DMAX; k++) {
+                    if (k < deg) {
+                        const int rot = kM - (int)e1[k];   // S0 = 360*g + rot, thr = 360 - rot
+                        const int g360 = (int)e0[k] - rot;
+                        const int t0 = wrap360(32 * w + rot);
+                        const uint32_t* p = sv + (g360 / kM) * kSvWords + (t0 >> 5);
+                        uint32_t x = __funnelshift_r(p[0], p[1], t0 & 31);
+                        if (i == 0 && k == deg - 1 && w == 0) x &= ~1u; // check (0,0): no previous parity
+                        acc ^= x;
+                    }
                 }
                 if (w == 11) acc &= 0xffu;
                 bad |= acc != 0;
@@ -243,7 +360,8 @@ __global__ __launch_bounds__(kThreads) void ldpc_layered_kernel(
             uint32_t ent[2 * DMAX];
 #pragma unroll
             for (int k = 0; k < 2 * DMAX; k++) ent[k] = rec[4 + k];
-            const int deg = (int)(hdr & 0x7fffu) + 2;
+            const int deg = (int)(hdr & 0xffu) + 2;
+            const int nc = (int)((hdr >> 8) & 0xfu);
             const int block = (int)(hdr >> 16);
             const bool layer0 = (i == 0);
             uint32_t* mp = msg_base + (size_t)i * MW * kMsgStride;
@@ -267,36 +385,43 @@ __global__ __launch_bounds__(kThreads) void ldpc_layered_kernel(
                 }
                 TSTAMP(tC); tm_body += tC - tB;
             } else {
-                // sequential-order hazard inside the layer (ldpc_schedule.h): the first wave of the half walks the
-                // 360 checks alone in ascending chunks of min(B_i, 64); LDS operations of one wave execute in
-                // order, so the chunks need no barrier between them.
-                if (!finished && wave == 0) {
-                    const int chunk = block < 64 ? block : 64;
-                    uint32_t nx[MW];
-                    if (lane < chunk) {
+                if (nc != kHazardWalk) {
+                    // sequential-order hazard inside the layer: check_node_hazard (every thread takes every barrier)
+                    const int jj = tid;
+                    uint32_t mw[MW], nm[MW];
 #pragma unroll
-                        for (int w = 0; w < MW; w++) nx[w] = mp[w * kMsgStride + lane];
+                    for (int w = 0; w < MW; w++) mw[w] = work ? pre[w] : 0x80808080u;
+                    if (work && i + 1 < q) {
+#pragma unroll
+                        for (int w = 0; w < MW; w++) pre[w] = mp[(MW + w) * kMsgStride + tid];
                     }
-                    for (int start = 0; start < kM; start += chunk) {
-                        const int jj = start + lane;
-                        if (lane < chunk && jj < kM) {
-                            uint32_t mw[MW], nm[MW];
+                    DVBS2_HAZ_SWITCH
+                    if (work) {
 #pragma unroll
-                            for (int w = 0; w < MW; w++) mw[w] = nx[w];
-                            if (jj + chunk < kM) {
+                        for (int w = 0; w < MW; w++) mp[w * kMsgStride + jj] = nm[w];
+                    }
+                } else {
+                    // too many hazard entries: the first wave of the half walks the 360 checks alone in ascending
+                    // chunks of min(B_i, 64) (LDS operations of one wave execute in order: no barrier between chunks)
+                    if (!finished && wave == 0) {
+                        const int chunk = block < 64 ? block : 64;
+                        for (int start = 0; start < kM; start += chunk) {
+                            const int jj = start + lane;
+                            if (lane < chunk && jj < kM) {
+                                uint32_t mw[MW], nm[MW];
 #pragma unroll
-                                for (int w = 0; w < MW; w++) nx[w] = mp[w * kMsgStride + jj + chunk];
+                                for (int w = 0; w < MW; w++) mw[w] = mp[w * kMsgStride + jj];
+                                DVBS2_DEG_SWITCH
+#pragma unroll
+                                for (int w = 0; w < MW; w++) mp[w * kMsgStride + jj] = nm[w];
                             }
-                            DVBS2_DEG_SWITCH
-#pragma unroll
-                            for (int w = 0; w < MW; w++) mp[w * kMsgStride + jj] = nm[w];
                         }
                     }
-                }
-                __syncthreads();
-                if (work && i + 1 < q) {
+                    __syncthreads();
+                    if (work && i + 1 < q) {
 #pragma unroll
-                    for (int w = 0; w < MW; w++) pre[w] = mp[(MW + w) * kMsgStride + tid];
+                        for (int w = 0; w < MW; w++) pre[w] = mp[(MW + w) * kMsgStride + tid];
+                    }
                 }
                 TSTAMP(tC); tm_conf += tC - tB;
             }
@@ -308,7 +433,7 @@ __global__ __launch_bounds__(kThreads) void ldpc_layered_kernel(
     }
     if (TIMING && tdbg && lane == 0 && have_frame) {
         unsigned long long* o = tdbg + ((size_t)f * 6 + wave) * 8;
-        o[0] = tm_load; o[1] = tm_synd; o[2] = tm_sweep; o[3] = tm_bar; o[4] = tm_body; o[5] = tm_conf; o[6] = (unsigned long long)it; o[7] = 0;
+        o[0] = tm_load; o[1] = tm_synd; o[2] = tm_sweep; o[3] = tm_bar; o[4] = tm_body; o[5] = tm_conf; o[6] = (unsigned long long)it; o[7] = tm_s1;
     }
 
     if (have_frame && !untouched) {
@@ -381,7 +506,12 @@ LdpcDecoderHip::LdpcDecoderHip(const LdpcTableDesc* table, int out_bits_message,
     std::vector<uint32_t> hr((size_t)sched_.q * RS, 0);
     for (int i = 0; i < sched_.q; i++) {
         const LdpcLayer& L = sched_.layers[i];
-        hr[(size_t)i * RS] = L.cnt | ((uint32_t)L.sync_before << 15) | ((uint32_t)L.block << 16);
+        uint32_t nc_code = 0;
+        if (L.block < 360) {
+            nc_code = L.n_conflict <= 2 ? 2 : L.n_conflict <= 4 ? 4 : 8;
+            if (L.n_conflict > kMaxHazard || (int)nc_code > L.cnt) nc_code = kHazardWalk;
+        }
+        hr[(size_t)i * RS] = L.cnt | (nc_code << 8) | ((uint32_t)L.sync_before << 15) | ((uint32_t)L.block << 16);
         for (int k = 0; k < L.cnt + 2; k++) {
             const LdpcEntry& e = sched_.entries[L.entry_off + k];
             hr[(size_t)i * RS + 4 + 2 * k] = (uint32_t)e.base + e.rot;
@@ -452,7 +582,7 @@ int LdpcDecoderHip::decode_device(const int8_t* d_llr_in, int n_frames, int max_
         double a[8] = {0};
         for (size_t r = 0; r < (size_t)n_frames * 6; r++) for (int c = 0; c < 8; c++) a[c] += (double)h[r * 8 + c];
         const double nr = (double)n_frames * 6;
-        fprintf(stderr, "[timing, 100MHz ticks per wave avg] load %.0f synd %.0f sweep %.0f (barrier %.0f body %.0f conflict-layers %.0f) iters %.1f\n", a[0]/nr, a[1]/nr, a[2]/nr, a[3]/nr, a[4]/nr, a[5]/nr, a[6]/nr);
+        fprintf(stderr, "[timing, 100MHz ticks per wave avg] load %.0f synd %.0f sweep %.0f (barrier %.0f body %.0f conflict-layers %.0f) iters %.1f synd-step1 %.0f\n", a[0]/nr, a[1]/nr, a[2]/nr, a[3]/nr, a[4]/nr, a[5]/nr, a[6]/nr, a[7]/nr);
     }
     const int n_groups = (n_frames + G_ - 1) / G_;
     for (int round = 0;; round++) {

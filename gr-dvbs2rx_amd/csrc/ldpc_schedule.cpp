@@ -58,9 +58,18 @@ bool compile_ldpc_schedule(const LdpcTableDesc* t, LdpcSchedule* out)
         L.sync_before = hit ? 1 : 0;
         if (hit) epoch.clear();
         epoch.insert(mine.begin(), mine.end());
-        if (block < 360) epoch.clear(); // a sub-blocked layer ends with a barrier of its own
 
-        for (const GS& e : v)
+        // hazard entries first
+        std::vector<GS> ordered;
+        int n_conf = 0;
+        for (int pass = 0; pass < 2; pass++)
+            for (size_t a = 0; a < v.size(); a++) {
+                int same = 0;
+                for (size_t b = 0; b < v.size(); b++) same += v[b].g == v[a].g;
+                if ((same > 1) == (pass == 0)) { ordered.push_back(v[a]); n_conf += pass == 0; }
+            }
+        L.n_conflict = (uint16_t)n_conf;
+        for (const GS& e : ordered)
             s.entries.push_back({ (uint16_t)(360 * e.g), (uint16_t)((360 - e.sh) % 360) });
         // own parity pty[360*i + j]
         s.entries.push_back({ (uint16_t)(s.K + 360 * i), 0 });

@@ -29,6 +29,8 @@ struct LdpcLayer {
     uint32_t entry_off; // first entry in LdpcSchedule::entries (cnt data entries, then own parity, then previous parity)
     uint16_t cnt;       // data entries (check degree = cnt + 2; check (0,0) has no previous parity)
     uint16_t block;     // B_i: 360 when the layer has no intra-layer hazard
+    uint16_t n_conflict;  // hazard layers: the first n_conflict data entries are the ones whose group occurs more
+                          // than once in the layer (entry order inside a check does not affect the result)
     uint16_t sync_before; // 1: a workgroup barrier is required before this layer (it touches a group that a
                           // layer since the previous barrier also touches through a different lane mapping)
 };
