@@ -1,0 +1,456 @@
+// ldpc_kernel.hpp -- device code of the layered LDPC decoder (included by ldpc_hip.hip for the constants and by
+// the per-variant translation units ldpc_inst_*.hip, which instantiate one DMAX each so that the seven kernel
+// variants compile in parallel).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+namespace dvbs2 {
+
+// Thread mapping: a workgroup of 12 wavefronts decodes a PAIR of FECFRAMEs in lockstep; wavefronts 0-5 own
+// frame 2b, wavefronts 6-11 own frame 2b+1. Inside a half, thread t (< 360) owns check row t of every
+// circulant layer. Two frames are what the 160 KB of LDS hold (2 x (64800 + 9360) bytes for normal frames);
+// putting them in ONE workgroup makes the hardware spread its 12 waves 3 per SIMD, all in the same phase of
+// the same layer, so the per-layer barrier costs no load-imbalance wait (two independent 6-wave workgroups
+// land 2,2,1,1 on the SIMDs and spend a quarter of their time waiting for the doubly loaded ones).
+constexpr int kHalf = 384;          // threads per frame (6 wavefronts; threads 0..359 active)
+constexpr int kThreads = 2 * kHalf; // 12 wavefronts
+constexpr int kM = 360;
+constexpr int kMsgStride = 384;     // message slots per (layer, word)
+constexpr int kSvWords = 14;        // sign-vector dwords per 360-bit group (360 bits + 32-bit wrap extension, even for b64 stores)
+
+// Layer record (uniform data, read with scalar loads): RS = 2*DMAX + 4 dwords.
+//   word 0: cnt | sync_before << 15 | block << 16
+//   words 4+2k, 5+2k (k < deg): entry k as  S0 = 360*g + rot  and  thr = 360 - rot
+// Entry k addresses the LDS window [360*g, 360*g + 360) rotated by rot: check row j touches byte
+// 360*g + (j + rot) mod 360 = (j < thr ? S0 + j : S0 + j - 360).
+__host__ __device__ constexpr int rec_stride(int dmax) { return 2 * dmax + 4; }
+__host__ __device__ constexpr size_t half_lds_bytes(int N) { return ((size_t)N + (size_t)(N / kM) * kSvWords * 4 + 32 + 15) / 16 * 16; }
+
+__device__ __forceinline__ int wrap360(int t) { return t >= kM ? t - kM : t; }
+
+// One check node (layered_decoder.hh:56-77 + algorithms.hh:170-192,203-206), fully unrolled for its degree.
+// LLRs are offset-binary bytes Lb = L + 128 in LDS; messages are offset-binary bytes, 4 per dword.
+// The kernel is VALU-issue bound (not HBM bound): ~22 VALU + 2 LDS instructions per edge.
+template <int DEG, bool LAYER0>
+__device__ __forceinline__ void check_node(uint8_t* __restrict__ lds, const uint32_t* ent /*uniform: S0, thr pairs*/,
+                                           int jj, const uint32_t* mw, uint32_t* nm)
+{
+    int ad[DEG], Lb[DEG];
+#pragma unroll
+    for (int k = 0; k < DEG; k++) {
+        // address = S0 + jj, minus 360 when jj >= thr; the two parity entries have rot = 0 (never wrap) except
+        // the previous-parity entry of layer 0 (rot = 359)
+        if (k >= DEG - 2 && !(LAYER0 && k == DEG - 1)) ad[k] = jj + (int)ent[2 * k];
+        else ad[k] = jj + (int)ent[2 * k] - ((uint32_t)jj < ent[2 * k + 1] ? 0 : kM);
+    }
+#pragma unroll
+    for (int k = 0; k < DEG; k++) Lb[k] = lds[ad[k]];
+    // check (0,0) has no previous-parity link (layered_decoder.hh:56,63-66)
+    const bool last_valid = !LAYER0 || jj != 0;
+
+    int inp[DEG], mg[DEG];
+    int min0 = 127, min1 = 127, signs = 0;
+#pragma unroll
+    for (int k = 0; k < DEG; k++) {
+        const int mb = (int)((mw[k >> 2] >> (8 * (k & 3))) & 0xffu);
+        // R1 inp = sat8(L - m); R2 mag = usat(qabs(inp) - 1) == med3(|L - m| - 1, 0, 126)
+        int d = min(max(Lb[k] - mb, -128), 127);
+        int mag = (int)__builtin_amdgcn_sad_u16((uint32_t)Lb[k], (uint32_t)mb, 0xffffffffu);
+        mag = min(max(mag, 0), 126);
+        if (LAYER0 && k == DEG - 1) { d = last_valid ? d : 0; mag = last_valid ? mag : 127; }
+        inp[k] = d; mg[k] = mag;
+        // R3 two smallest magnitudes (new min1 = median(min0, min1, mag)); R4 xor of the sign bits
+        min1 = min(max(mag, min0), min1);
+        min0 = min(min0, mag);
+        signs ^= d;
+    }
+#pragma unroll
+    for (int w = 0; w < (DEG + 3) / 4; w++) nm[w] = 0;
+    const int s01 = min0 + min1;
+#pragma unroll
+    for (int k = 0; k < DEG; k++) {
+        // R5 out = vsign(mag == min0 ? min1 : min0, (signs ^ x) | 127); mag is min0 or >= min1, so the selected
+        // magnitude is min0 + min1 - min(mag, min1)
+        const int other = s01 - min(mg[k], min1);
+        const int sg = (signs ^ inp[k]) >> 31;
+        const int out = (other ^ sg) - sg;
+        // R6 LLR = sat8(inp + out) with the unclamped out; R7 stored message = clamp(out, -32, 31)
+        const int nl = min(max(inp[k] + out + 128, 0), 255);
+        if (!(LAYER0 && k == DEG - 1) || last_valid) lds[ad[k]] = (uint8_t)nl;
+        const int nmsg = min(max(out, -32), 31) + 128;
+        nm[k >> 2] |= (uint32_t)nmsg << (8 * (k & 3));
+    }
+}
+
+// Hazard layer (two or more entries of one group, ldpc_schedule.h): the reference's strictly ordered update
+// makes check j see what checks j' < j wrote to the bits they share. Only the NC hazard entries (placed first)
+// carry that dependency, so the check node is split in three:
+//   P1  all 360 rows in parallel: regular entries are read and reduced to a partial (min0, min1, signs);
+//   P2  ascending blocks of B_i rows, one workgroup barrier per block: the rows of the block read their
+//       hazard bits (now final with respect to all earlier rows), complete (min0, min1, signs), and write the
+//       hazard bits back;
+//   P3  all rows in parallel: outputs of the regular entries.
+// The result is identical to the sequential order: inside a block no two rows share a bit, blocks ascend, and
+// a regular entry's bits are touched by exactly one row of the layer.
+// NC (2, 4 or 8) is the number of entries handled in P2: the hazard entries, rounded up with regular data entries
+// (moving a regular entry into the ordered part does not change the result).
+constexpr int kMaxHazard = 8;
+constexpr int kHazardWalk = 15; // header code: too many hazard entries, fall back to the single-wave chunk walk
+template <int DEG, int NC, bool LAYER0>
+__device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, const uint32_t* ent, int jj, bool work,
+                                                  int block, const uint32_t* mw, uint32_t* nm)
+{
+    int ad[DEG], inp[DEG], mg[DEG];
+    int min0 = 127, min1 = 127, signs = 0;
+    const bool last_valid = !LAYER0 || jj != 0;
+    if (work) {
+#pragma unroll
+        for (int k = 0; k < DEG; k++) {
+            if (k >= DEG - 2 && !(LAYER0 && k == DEG - 1)) ad[k] = jj + (int)ent[2 * k];
+            else ad[k] = jj + (int)ent[2 * k] - ((uint32_t)jj < ent[2 * k + 1] ? 0 : kM);
+        }
+#pragma unroll
+        for (int k = 0; k < DEG; k++) {
+            if (k >= NC) { // regular entry
+                const int Lb = lds[ad[k]];
+                const int mb = (int)((mw[k >> 2] >> (8 * (k & 3))) & 0xffu);
+                int d = min(max(Lb - mb, -128), 127);
+                int mag = (int)__builtin_amdgcn_sad_u16((uint32_t)Lb, (uint32_t)mb, 0xffffffffu);
+                mag = min(max(mag, 0), 126);
+                if (LAYER0 && k == DEG - 1) { d = last_valid ? d : 0; mag = last_valid ? mag : 127; }
+                inp[k] = d; mg[k] = mag;
+                min1 = min(max(mag, min0), min1);
+                min0 = min(min0, mag);
+                signs ^= d;
+            }
+        }
+    }
+#pragma unroll
+    for (int w = 0; w < (DEG + 3) / 4; w++) nm[w] = 0;
+    for (int start = 0; start < kM; start += block) {
+        if (work && jj >= start && jj < start + block) {
+            int Lh[NC];
+#pragma unroll
+            for (int k = 0; k < NC; k++) Lh[k] = lds[ad[k]];
+#pragma unroll
+            for (int k = 0; k < NC; k++) {
+                const int mb = (int)((mw[k >> 2] >> (8 * (k & 3))) & 0xffu);
+                const int d = min(max(Lh[k] - mb, -128), 127);
+                int mag = (int)__builtin_amdgcn_sad_u16((uint32_t)Lh[k], (uint32_t)mb, 0xffffffffu);
+                mag = min(max(mag, 0), 126);
+                inp[k] = d; mg[k] = mag;
+                min1 = min(max(mag, min0), min1);
+                min0 = min(min0, mag);
+                signs ^= d;
+            }
+#pragma unroll
+            for (int k = 0; k < NC; k++) {
+                const int other = (mg[k] == min0) ? min1 : min0;
+                const int sg = (signs ^ inp[k]) >> 31;
+                const int out = (other ^ sg) - sg;
+                lds[ad[k]] = (uint8_t)min(max(inp[k] + out + 128, 0), 255);
+                nm[k >> 2] |= (uint32_t)(min(max(out, -32), 31) + 128) << (8 * (k & 3));
+            }
+        }
+        // the next block reads what this one wrote: a workgroup barrier, unless both blocks sit inside one and the
+        // same wavefront (LDS operations of a wave execute in program order)
+        if ((start >> 6) != ((start + 2 * block - 1) >> 6)) __syncthreads();
+    }
+    __syncthreads();
+    if (work) {
+#pragma unroll
+        for (int k = 0; k < DEG; k++) {
+            if (k >= NC) {
+                const int other = (mg[k] == min0) ? min1 : min0;
+                const int sg = (signs ^ inp[k]) >> 31;
+                const int out = (other ^ sg) - sg;
+                const int nl = min(max(inp[k] + out + 128, 0), 255);
+                if (!(LAYER0 && k == DEG - 1) || last_valid) lds[ad[k]] = (uint8_t)nl;
+                nm[k >> 2] |= (uint32_t)(min(max(out, -32), 31) + 128) << (8 * (k & 3));
+            }
+        }
+    }
+}
+
+// degrees DMAX-7 .. DMAX are instantiated for kernel variant DMAX
+#define DVBS2_DEG_CASE(D) case D: if constexpr (D >= 3 && D <= DMAX && D > DMAX - 8) { \
+        if (layer0) check_node<(D >= 3 ? D : 3), true>(lds, ent, jj, mw, nm); else check_node<(D >= 3 ? D : 3), false>(lds, ent, jj, mw, nm); } break;
+#define DVBS2_DEG_SWITCH switch (deg) { \
+        DVBS2_DEG_CASE(3) DVBS2_DEG_CASE(4) DVBS2_DEG_CASE(5) DVBS2_DEG_CASE(6) DVBS2_DEG_CASE(7) DVBS2_DEG_CASE(8) \
+        DVBS2_DEG_CASE(9) DVBS2_DEG_CASE(10) DVBS2_DEG_CASE(11) DVBS2_DEG_CASE(12) DVBS2_DEG_CASE(13) DVBS2_DEG_CASE(14) \
+        DVBS2_DEG_CASE(15) DVBS2_DEG_CASE(16) DVBS2_DEG_CASE(17) DVBS2_DEG_CASE(18) DVBS2_DEG_CASE(19) DVBS2_DEG_CASE(20) \
+        DVBS2_DEG_CASE(21) DVBS2_DEG_CASE(22) DVBS2_DEG_CASE(23) DVBS2_DEG_CASE(24) DVBS2_DEG_CASE(25) DVBS2_DEG_CASE(26) \
+        DVBS2_DEG_CASE(27) DVBS2_DEG_CASE(28) DVBS2_DEG_CASE(29) DVBS2_DEG_CASE(30) DVBS2_DEG_CASE(31) DVBS2_DEG_CASE(32) \
+        default: break; }
+
+#define DVBS2_HAZ_CALL(D, NCV) { if constexpr (D - 2 >= NCV) { \
+        if (layer0) check_node_hazard<D, NCV, true>(lds, ent, jj, work, block, mw, nm); else check_node_hazard<D, NCV, false>(lds, ent, jj, work, block, mw, nm); } }
+#define DVBS2_HAZ_CASE(D) case D: if constexpr (D >= 4 && D <= DMAX && D > DMAX - 8) { \
+        if (nc == 2) DVBS2_HAZ_CALL((D >= 4 ? D : 4), 2) else if (nc == 4) DVBS2_HAZ_CALL((D >= 4 ? D : 4), 4) else DVBS2_HAZ_CALL((D >= 4 ? D : 4), 8) } break;
+#define DVBS2_HAZ_SWITCH switch (deg) { \
+        DVBS2_HAZ_CASE(4) DVBS2_HAZ_CASE(5) DVBS2_HAZ_CASE(6) DVBS2_HAZ_CASE(7) DVBS2_HAZ_CASE(8) \
+        DVBS2_HAZ_CASE(9) DVBS2_HAZ_CASE(10) DVBS2_HAZ_CASE(11) DVBS2_HAZ_CASE(12) DVBS2_HAZ_CASE(13) DVBS2_HAZ_CASE(14) \
+        DVBS2_HAZ_CASE(15) DVBS2_HAZ_CASE(16) DVBS2_HAZ_CASE(17) DVBS2_HAZ_CASE(18) DVBS2_HAZ_CASE(19) DVBS2_HAZ_CASE(20) \
+        DVBS2_HAZ_CASE(21) DVBS2_HAZ_CASE(22) DVBS2_HAZ_CASE(23) DVBS2_HAZ_CASE(24) DVBS2_HAZ_CASE(25) DVBS2_HAZ_CASE(26) \
+        DVBS2_HAZ_CASE(27) DVBS2_HAZ_CASE(28) DVBS2_HAZ_CASE(29) DVBS2_HAZ_CASE(30) DVBS2_HAZ_CASE(31) DVBS2_HAZ_CASE(32) \
+        default: break; }
+
+template <int DMAX, bool TIMING>
+__global__ __launch_bounds__(kThreads) void ldpc_layered_kernel(
+    const uint32_t* __restrict__ recs, const int8_t* __restrict__ llr_in, uint8_t* __restrict__ state,
+    uint32_t* __restrict__ msgs, int* __restrict__ iters, int* __restrict__ good, const int* __restrict__ target,
+    int n_frames, int N, int K, int q, int cap, int stop_on_good, unsigned long long* __restrict__ tdbg)
+{
+    unsigned long long tm_bar = 0, tm_body = 0, tm_conf = 0, tm_synd = 0, tm_sweep = 0, tm_load = 0, tm_s1 = 0;
+#define TSTAMP(x) do { if (TIMING) { x = __builtin_readcyclecounter(); } } while (0)
+    unsigned long long tA = 0, tB = 0, tC = 0, tS0 = 0, tS1 = 0;
+    TSTAMP(tA);
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_all[];
+    constexpr int RS = rec_stride(DMAX);
+    constexpr int MW = DMAX / 4; // message dwords per check (fixed per kernel variant)
+    const int half = __builtin_amdgcn_readfirstlane(threadIdx.x >= kHalf ? 1 : 0); // wave-uniform, and the compiler knows it
+    const int tid = threadIdx.x - half * kHalf;
+    uint8_t* lds = lds_all + half * half_lds_bytes(N);
+    uint32_t* sv = reinterpret_cast<uint32_t*>(lds + N); // N % 8 == 0
+    volatile int* flags = reinterpret_cast<volatile int*>(sv + (N / kM) * kSvWords); // [0] bad-or, [1] finished
+    volatile int* other_flags = reinterpret_cast<volatile int*>(
+        lds_all + (1 - half) * half_lds_bytes(N) + N + (size_t)(N / kM) * kSvWords * 4);
+    const int f = 2 * blockIdx.x + half;
+    const bool have_frame = f < n_frames;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int NG = N / kM;
+    const bool active = tid < kM;
+
+    int it = 0, tgt = 0;
+    bool finished = !have_frame; // this half has nothing (more) to do; it still takes part in every barrier
+    if (have_frame) {
+        tgt = target ? target[f] : cap;
+        if (llr_in) {
+            const uint2* src = reinterpret_cast<const uint2*>(llr_in + (size_t)f * N);
+            for (int c = tid; c < N / 8; c += kHalf) {
+                uint2 v = src[c];
+                v.x ^= 0x80808080u; v.y ^= 0x80808080u;
+                const int n = 8 * c;
+                if (n < K) *reinterpret_cast<uint2*>(lds + n) = v; // K % 8 == 0
+                else {
+                    // pty[360*i + j] = parity[q*j + i] (layered_decoder.hh:150-152)
+                    int r = n - K;
+                    int jq = r / q, iq = r - jq * q;
+#pragma unroll
+                    for (int b = 0; b < 8; b++) {
+                        lds[K + kM * iq + jq] = (uint8_t)((b < 4 ? v.x >> (8 * b) : v.y >> (8 * (b - 4))) & 0xffu);
+                        if (++iq == q) { iq = 0; ++jq; }
+                    }
+                }
+            }
+        } else {
+            it = iters[f];
+            if (it >= tgt) finished = true; // nothing to do for this frame in this pass
+            else {
+                const uint2* src = reinterpret_cast<const uint2*>(state + (size_t)f * N);
+                for (int c = tid; c < N / 8; c += kHalf) *reinterpret_cast<uint2*>(lds + 8 * c) = src[c];
+            }
+        }
+    }
+    const bool untouched = finished; // never loaded: must not write state/iters/good back
+    if (tid == 0) { flags[0] = 0; flags[1] = finished ? 1 : 0; }
+    __syncthreads();
+    TSTAMP(tB); tm_load = tB - tA;
+
+    uint32_t* msg_base = msgs + (size_t)(have_frame ? f : 0) * q * MW * kMsgStride;
+    bool is_good = false;
+
+    for (;;) {
+        TSTAMP(tS0);
+        // ---- syndrome test (layered_decoder.hh:32-49, algorithms.hh:195-202): bad if any check has a zero
+        // LLR or an odd number of negative LLRs. Barriers are taken by every thread; work only by halves that need it.
+        const bool need_synd = !finished && (stop_on_good || it >= tgt);
+        if (need_synd) {
+            // Step 1: 360-bit sign vector per group via wave ballots (4 groups per trip to batch the LDS reads).
+            unsigned long long zero_any = 0;
+            for (int g0 = 0; g0 < NG; g0 += 4) {
+                uint32_t v[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) v[u] = (active && g0 + u < NG) ? lds[kM * (g0 + u) + tid] : 0xffu;
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const unsigned long long neg = __ballot(v[u] < 0x80u);
+                    zero_any |= __ballot(v[u] == 0x80u);
+                    if (lane == 0 && g0 + u < NG) *reinterpret_cast<uint2*>(&sv[(g0 + u) * kSvWords + 2 * wave]) = make_uint2((uint32_t)neg, (uint32_t)(neg >> 32));
+                }
+            }
+            if (zero_any != 0 && lane == 0) flags[0] = 1;
+        }
+        TSTAMP(tC); tm_s1 += tC - tS0;
+        __syncthreads();
+        if (need_synd && tid < NG) { // wrap extension: bits 360+u = bit u
+            uint32_t* p = sv + tid * kSvWords;
+            const uint32_t w0 = p[0], w1 = p[1];
+            p[11] = (p[11] & 0xffu) | (w0 << 8);
+            p[12] = (w0 >> 24) | (w1 << 8);
+        }
+        __syncthreads();
+        if (need_synd) {
+            // Step 2: parity word (layer i, lanes 32w..32w+31) = xor over entries of the rotated sign vectors
+            int bad = 0;
+            for (int item = tid; item < q * 12; item += kHalf) {
+                const int i = item / 12, w = item - 12 * i;
+                const uint32_t* rec = recs + (size_t)i * RS;
+                const int deg = (int)(rec[0] & 0xffu) + 2;
+                uint32_t e0[DMAX], e1[DMAX];
+#pragma unroll
+                for (int k = 0; k < DMAX; k++) { e0[k] = rec[4 + 2 * k]; e1[k] = rec[5 + 2 * k]; } // padded records: always readable
+                uint32_t acc = 0;
+#pragma unroll
+                for (int k = 0; k < DMAX; k++) {
+                    if (k < deg) {
+                        const int rot = kM - (int)e1[k];   // S0 = 360*g + rot, thr = 360 - rot
+                        const int g360 = (int)e0[k] - rot;
+                        const int t0 = wrap360(32 * w + rot);
+                        const uint32_t* p = sv + (g360 / kM) * kSvWords + (t0 >> 5);
+                        uint32_t x = __funnelshift_r(p[0], p[1], t0 & 31);
+                        if (i == 0 && k == deg - 1 && w == 0) x &= ~1u; // check (0,0): no previous parity
+                        acc ^= x;
+                    }
+                }
+                if (w == 11) acc &= 0xffu;
+                bad |= acc != 0;
+            }
+            if (__ballot(bad) != 0 && lane == 0) flags[0] = 1;
+        }
+        __syncthreads();
+        if (need_synd) is_good = flags[0] == 0;
+        if (!finished && (it >= tgt || (stop_on_good && is_good))) finished = true;
+        __syncthreads(); // everyone has read flags[0]
+        if (tid == 0) { flags[0] = 0; flags[1] = finished ? 1 : 0; }
+        __syncthreads();
+        TSTAMP(tS1); tm_synd += tS1 - tS0;
+        if (finished && other_flags[1]) break; // uniform over the workgroup
+
+        // ---- one update sweep: layered_decoder.hh:50-79 ----
+        const bool work = !finished && active;
+        uint32_t pre[MW]; // messages of the next layer for check tid, loaded one layer ahead
+        if (work) {
+#pragma unroll
+            for (int w = 0; w < MW; w++) pre[w] = msg_base[w * kMsgStride + tid];
+        }
+        for (int i = 0; i < q; i++) {
+            const uint32_t* rec = recs + (size_t)i * RS;
+            const uint32_t hdr = rec[0];
+            uint32_t ent[2 * DMAX];
+#pragma unroll
+            for (int k = 0; k < 2 * DMAX; k++) ent[k] = rec[4 + k];
+            const int deg = (int)(hdr & 0xffu) + 2;
+            const int nc = (int)((hdr >> 8) & 0xfu);
+            const int block = (int)(hdr >> 16);
+            const bool layer0 = (i == 0);
+            uint32_t* mp = msg_base + (size_t)i * MW * kMsgStride;
+            TSTAMP(tA);
+            if (hdr & 0x8000u) __syncthreads();
+            TSTAMP(tB); tm_bar += tB - tA;
+            if (block >= kM) {
+                // regular layer: all 360 checks at once
+                if (work) {
+                    const int jj = tid;
+                    uint32_t mw[MW], nm[MW];
+#pragma unroll
+                    for (int w = 0; w < MW; w++) mw[w] = pre[w];
+                    if (i + 1 < q) {
+#pragma unroll
+                        for (int w = 0; w < MW; w++) pre[w] = mp[(MW + w) * kMsgStride + tid];
+                    }
+                    DVBS2_DEG_SWITCH
+#pragma unroll
+                    for (int w = 0; w < MW; w++) mp[w * kMsgStride + jj] = nm[w];
+                }
+                TSTAMP(tC); tm_body += tC - tB;
+            } else {
+                if (nc != kHazardWalk) {
+                    // sequential-order hazard inside the layer: check_node_hazard (every thread takes every barrier)
+                    const int jj = tid;
+                    uint32_t mw[MW], nm[MW];
+#pragma unroll
+                    for (int w = 0; w < MW; w++) mw[w] = work ? pre[w] : 0x80808080u;
+                    if (work && i + 1 < q) {
+#pragma unroll
+                        for (int w = 0; w < MW; w++) pre[w] = mp[(MW + w) * kMsgStride + tid];
+                    }
+                    DVBS2_HAZ_SWITCH
+                    if (work) {
+#pragma unroll
+                        for (int w = 0; w < MW; w++) mp[w * kMsgStride + jj] = nm[w];
+                    }
+                } else {
+                    // too many hazard entries: the first wave of the half walks the 360 checks alone in ascending
+                    // chunks of min(B_i, 64) (LDS operations of one wave execute in order: no barrier between chunks)
+                    if (!finished && wave == 0) {
+                        const int chunk = block < 64 ? block : 64;
+                        for (int start = 0; start < kM; start += chunk) {
+                            const int jj = start + lane;
+                            if (lane < chunk && jj < kM) {
+                                uint32_t mw[MW], nm[MW];
+#pragma unroll
+                                for (int w = 0; w < MW; w++) mw[w] = mp[w * kMsgStride + jj];
+                                DVBS2_DEG_SWITCH
+#pragma unroll
+                                for (int w = 0; w < MW; w++) mp[w * kMsgStride + jj] = nm[w];
+                            }
+                        }
+                    }
+                    __syncthreads();
+                    if (work && i + 1 < q) {
+#pragma unroll
+                        for (int w = 0; w < MW; w++) pre[w] = mp[(MW + w) * kMsgStride + tid];
+                    }
+                }
+                TSTAMP(tC); tm_conf += tC - tB;
+            }
+        }
+        TSTAMP(tA);
+        __syncthreads();
+        TSTAMP(tB); tm_bar += tB - tA; tm_sweep += tB - tS1;
+        if (!finished) it++;
+    }
+    if (TIMING && tdbg && lane == 0 && have_frame) {
+        unsigned long long* o = tdbg + ((size_t)f * 6 + wave) * 8;
+        o[0] = tm_load; o[1] = tm_synd; o[2] = tm_sweep; o[3] = tm_bar; o[4] = tm_body; o[5] = tm_conf; o[6] = (unsigned long long)it; o[7] = tm_s1;
+    }
+
+    if (have_frame && !untouched) {
+        if (tid == 0) { iters[f] = it; good[f] = is_good ? 1 : 0; }
+        uint2* dst = reinterpret_cast<uint2*>(state + (size_t)f * N);
+        for (int c = tid; c < N / 8; c += kHalf) dst[c] = *reinterpret_cast<const uint2*>(lds + 8 * c);
+    }
+}
+
+
+// ---- host-side launch interface of one kernel variant (defined in ldpc_inst_*.hip) ----
+struct LdpcLaunch {
+    const uint32_t* recs; const int8_t* llr_in; uint8_t* state; uint32_t* msgs; int* iters; int* good; const int* target;
+    int n_frames, N, K, q, cap, stop_on_good; unsigned long long* tdbg;
+    size_t lds_bytes; hipStream_t stream;
+};
+template <int DMAX> hipError_t ldpc_variant_prepare(size_t lds_bytes);
+template <int DMAX> void ldpc_variant_launch(const LdpcLaunch& a);
+
+#ifdef DVBS2_LDPC_INSTANTIATE
+template <int DMAX> hipError_t ldpc_variant_prepare(size_t lds_bytes)
+{
+    hipError_t e = hipFuncSetAttribute((const void*)ldpc_layered_kernel<DMAX, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute((const void*)ldpc_layered_kernel<DMAX, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+}
+template <int DMAX> void ldpc_variant_launch(const LdpcLaunch& a)
+{
+    const dim3 grid((a.n_frames + 1) / 2), block(kThreads);
+    if (a.tdbg) hipLaunchKernelGGL((ldpc_layered_kernel<DMAX, true>), grid, block, a.lds_bytes, a.stream, a.recs, a.llr_in, a.state, a.msgs,
+                                   a.iters, a.good, a.target, a.n_frames, a.N, a.K, a.q, a.cap, a.stop_on_good, a.tdbg);
+    else hipLaunchKernelGGL((ldpc_layered_kernel<DMAX, false>), grid, block, a.lds_bytes, a.stream, a.recs, a.llr_in, a.state, a.msgs,
+                            a.iters, a.good, a.target, a.n_frames, a.N, a.K, a.q, a.cap, a.stop_on_good, a.tdbg);
+}
+template hipError_t ldpc_variant_prepare<DVBS2_LDPC_INSTANTIATE>(size_t);
+template void ldpc_variant_launch<DVBS2_LDPC_INSTANTIATE>(const LdpcLaunch&);
+#endif
+
+} // namespace dvbs2
