@@ -213,7 +213,7 @@ __global__ __launch_bounds__(kThreads) void ldpc_layered_kernel(
     const int tid = threadIdx.x - half * kHalf;
     uint8_t* lds = lds_all + half * half_lds_bytes(N);
     uint32_t* sv = reinterpret_cast<uint32_t*>(lds + N); // N % 8 == 0
-    volatile int* flags = reinterpret_cast<volatile int*>(sv + (N / kM) * kSvWords); // [0] bad-or, [1] finished
+    volatile int* flags = reinterpret_cast<volatile int*>(sv + (N / kM) * kSvWords); // [0] bad-or, [1] finished, [2] pre-test failed, [3] full test needed
     volatile int* other_flags = reinterpret_cast<volatile int*>(
         lds_all + (1 - half) * half_lds_bytes(N) + N + (size_t)(N / kM) * kSvWords * 4);
     const int f = 2 * blockIdx.x + half;
@@ -254,7 +254,7 @@ __global__ __launch_bounds__(kThreads) void ldpc_layered_kernel(
         }
     }
     const bool untouched = finished; // never loaded: must not write state/iters/good back
-    if (tid == 0) { flags[0] = 0; flags[1] = finished ? 1 : 0; }
+    if (tid == 0) { flags[0] = 0; flags[2] = 0; flags[3] = 0; flags[1] = finished ? 1 : 0; }
     __syncthreads();
     TSTAMP(tB); tm_load = tB - tA;
 
@@ -266,7 +266,31 @@ __global__ __launch_bounds__(kThreads) void ldpc_layered_kernel(
         // ---- syndrome test (layered_decoder.hh:32-49, algorithms.hh:195-202): bad if any check has a zero
         // LLR or an odd number of negative LLRs. Barriers are taken by every thread; work only by halves that need it.
         const bool need_synd = !finished && (stop_on_good || it >= tgt);
-        if (need_synd) {
+        // Pre-test (the reference's bad() also returns at the first failing check): the 360 checks of ONE layer,
+        // tested edge by edge. A failure here is final; only a frame that passes pays for the full test below.
+        if (need_synd && active) {
+            const int i0 = it % q;
+            const uint32_t* rec = recs + (size_t)i0 * RS;
+            const int deg = (int)(rec[0] & 0xffu) + 2;
+            uint32_t x = 0, z = 0;
+            for (int k = 0; k < deg; k++) {
+                const int a0 = tid + (int)rec[4 + 2 * k] - ((uint32_t)tid < rec[5 + 2 * k] ? 0 : kM);
+                uint32_t v = lds[a0];
+                if (i0 == 0 && k == deg - 1 && tid == 0) v = 0x81u; // check (0,0) has no previous parity: neutral +1
+                x ^= v;
+                z |= (v == 0x80u);
+            }
+            // offset binary: the sign bit is inverted, so the count of negatives is deg - popcount(bit 7)
+            const int bad_pre = (int)((((x >> 7) ^ (uint32_t)deg) & 1u) | z);
+            if (__ballot(bad_pre) != 0 && lane == 0) flags[2] = 1;
+        }
+        __syncthreads();
+        const bool need_full = need_synd && flags[2] == 0;
+        if (tid == 0) flags[3] = need_full ? 1 : 0;
+        __syncthreads();
+        const bool full_any = flags[3] != 0 || other_flags[3] != 0; // uniform over the workgroup
+        if (full_any) {
+        if (need_full) {
             // Step 1: 360-bit sign vector per group via wave ballots (4 groups per trip to batch the LDS reads).
             unsigned long long zero_any = 0;
             for (int g0 = 0; g0 < NG; g0 += 4) {
@@ -284,14 +308,14 @@ __global__ __launch_bounds__(kThreads) void ldpc_layered_kernel(
         }
         TSTAMP(tC); tm_s1 += tC - tS0;
         __syncthreads();
-        if (need_synd && tid < NG) { // wrap extension: bits 360+u = bit u
+        if (need_full && tid < NG) { // wrap extension: bits 360+u = bit u
             uint32_t* p = sv + tid * kSvWords;
             const uint32_t w0 = p[0], w1 = p[1];
             p[11] = (p[11] & 0xffu) | (w0 << 8);
             p[12] = (w0 >> 24) | (w1 << 8);
         }
         __syncthreads();
-        if (need_synd) {
+        if (need_full) {
             // Step 2: parity word (layer i, lanes 32w..32w+31) = xor over entries of the rotated sign vectors
             int bad = 0;
             for (int item = tid; item < q * 12; item += kHalf) {
@@ -320,10 +344,11 @@ __global__ __launch_bounds__(kThreads) void ldpc_layered_kernel(
             if (__ballot(bad) != 0 && lane == 0) flags[0] = 1;
         }
         __syncthreads();
-        if (need_synd) is_good = flags[0] == 0;
+        } // full_any
+        if (need_synd) is_good = need_full && flags[0] == 0;
         if (!finished && (it >= tgt || (stop_on_good && is_good))) finished = true;
         __syncthreads(); // everyone has read flags[0]
-        if (tid == 0) { flags[0] = 0; flags[1] = finished ? 1 : 0; }
+        if (tid == 0) { flags[0] = 0; flags[2] = 0; flags[1] = finished ? 1 : 0; }
         __syncthreads();
         TSTAMP(tS1); tm_synd += tS1 - tS0;
         if (finished && other_flags[1]) break; // uniform over the workgroup
@@ -335,12 +360,26 @@ __global__ __launch_bounds__(kThreads) void ldpc_layered_kernel(
 #pragma unroll
             for (int w = 0; w < MW; w++) pre[w] = msg_base[w * kMsgStride + tid];
         }
+        // Layer records are double-buffered in SGPRs: the scalar loads of layer i+1 are issued at the top of layer i
+        // (an un-prefetched s_load at the head of every layer was a quarter of the sweep time). Small records are
+        // buffered whole; for the large ones only every 8th dword is carried over -- enough to pull each cache
+        // line of the next record into the scalar cache -- and the rest is loaded at the top of the layer.
+        constexpr int PF = DMAX <= 12 ? 1 : 8;
+        uint32_t nhdr = recs[0];
+        uint32_t nent[2 * DMAX];
+#pragma unroll
+        for (int k = 0; k < 2 * DMAX; k += PF) nent[k] = recs[4 + k];
         for (int i = 0; i < q; i++) {
-            const uint32_t* rec = recs + (size_t)i * RS;
-            const uint32_t hdr = rec[0];
+            const uint32_t hdr = nhdr;
             uint32_t ent[2 * DMAX];
 #pragma unroll
-            for (int k = 0; k < 2 * DMAX; k++) ent[k] = rec[4 + k];
+            for (int k = 0; k < 2 * DMAX; k++) ent[k] = (k % PF == 0) ? nent[k] : recs[(size_t)i * RS + 4 + k];
+            {
+                const uint32_t* nrec = recs + (size_t)(i + 1 < q ? i + 1 : 0) * RS;
+                nhdr = nrec[0];
+#pragma unroll
+                for (int k = 0; k < 2 * DMAX; k += PF) nent[k] = nrec[4 + k];
+            }
             const int deg = (int)(hdr & 0xffu) + 2;
             const int nc = (int)((hdr >> 8) & 0xfu);
             const int block = (int)(hdr >> 16);
