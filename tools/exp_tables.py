@@ -23,4 +23,5 @@ def run(table, nf=1024, trials=10, G=32):
     print(f"{table:14s} q={info['q']:3d} conf={info['conflict_layers']:2d} nf={nf} trials={trials}: {dt*1e3:8.2f} ms  {nf/dt:9.0f} fr/s  {edges/dt/1e9:7.2f} Gedge/s  per-iter-per-frame {dt/trials/ (nf/512)*1e6:7.1f} us")
     dec.close()
 for t in sys.argv[1:]:
-    run(t)
+    a = t.split(':')
+    run(a[0], nf=int(a[2]) if len(a) > 2 else 1024, trials=int(a[1]) if len(a) > 1 else 10)
