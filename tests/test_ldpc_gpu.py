@@ -115,3 +115,47 @@ def test_device_pointer_entry():
     assert np.array_equal(d_llr.cpu().numpy(), want)
     assert np.array_equal(d_bits.cpu().numpy(), T.pack_bits(want, K))
     dec.close()
+
+
+def test_every_table_of_the_reference():
+    """All 57 parity tables (every kernel variant / degree case): 3 updates on never-converging input plus a clean
+    codeword, against the genuine reference (oracle for G=32 when oracle/_ref is absent: slower but identical)."""
+    import json, os
+    rows = json.load(open(os.path.join(T.ROOT, "tests", "golden", "fec_params.json")))["rows"]
+    tables = sorted({r["table"] for r in rows})
+    assert len(tables) == 57
+    fast = T.ref_ldpc() is not None
+    for table in tables:
+        N, K, _, _ = T.ldpc_info(table)
+        if not fast and N > 16200:
+            continue
+        x = T.llr_noise(32, N, 4242)
+        clean, _ = T.llr_codeword_awgn(table, 1, 7, amp=20, sigma=0.0)
+        x[31] = clean[0]
+        bits, out, ret = run_gpu(table, x, 32, 3)
+        want, wret = checker(table, x, 32, 3)
+        assert ret.tolist() == wret, table
+        assert np.array_equal(out, want), table
+
+
+def test_ragged_and_empty_batches():
+    """1 frame, odd counts (the second half of the last pair workgroup is empty), zero frames, too many frames."""
+    import ctypes as C
+    table = "S2_TABLE_C1"
+    N, K, _, _ = T.ldpc_info(table)
+    llr, _ = T.llr_codeword_awgn(table, 7, 123, amp=5, sigma=6.4)
+    dec = LdpcDecoder(table=table, message_bits=K, group_size=1, max_frames=7, max_trials=20, outputmode=capi.OM_CODEWORD)
+    for nf in (1, 3, 7):
+        bits, out, ret = dec.work(llr[:nf], want_llr=True)
+        want, wret = T.oracle_ldpc_decode(table, llr[:nf], 1, 20)
+        assert ret.tolist() == wret and np.array_equal(out, want) and np.array_equal(bits, T.pack_bits(want, N))
+    assert capi.lib.dvbs2_ldpc_decode(dec._h, None, 0, 20, 1, None, None, None) == capi.OK
+    buf = np.zeros((8, N), np.int8); ob = np.zeros((8, N // 8), np.uint8)
+    assert capi.lib.dvbs2_ldpc_decode(dec._h, buf.ctypes.data, 8, 20, 0, ob.ctypes.data, None, None) == capi.ESIZE
+    assert capi.lib.dvbs2_ldpc_decode(dec._h, buf.ctypes.data, 1, 0, 0, ob.ctypes.data, None, None) == capi.EINVAL
+    dec.close()
+    # one update only, and a cap the decoder never reaches
+    for trials in (1, 200):
+        bits, out, ret = run_gpu(table, llr[:4], 4, trials)
+        want, wret = T.oracle_ldpc_decode(table, llr[:4], 4, trials)
+        assert ret.tolist() == wret and np.array_equal(out, want)
