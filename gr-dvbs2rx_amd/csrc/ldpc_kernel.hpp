@@ -354,11 +354,14 @@ __global__ __launch_bounds__(kThreads) void ldpc_layered_kernel(
         if (finished && other_flags[1]) break; // uniform over the workgroup
 
         // ---- one update sweep: layered_decoder.hh:50-79 ----
-        const bool work = !finished && active;
+        // Threads 360..383 of a half mirror check row 359: same reads, same results, same (duplicate) writes. That
+        // keeps the whole sweep free of per-lane predicates: `work` is wave-uniform.
+        const bool work = !finished;
+        const int row = tid < kM ? tid : kM - 1;
         uint32_t pre[MW]; // messages of the next layer for check tid, loaded one layer ahead
         if (work) {
 #pragma unroll
-            for (int w = 0; w < MW; w++) pre[w] = msg_base[w * kMsgStride + tid];
+            for (int w = 0; w < MW; w++) pre[w] = msg_base[w * kMsgStride + row];
         }
         // Layer records are double-buffered in SGPRs: the scalar loads of layer i+1 are issued at the top of layer i
         // (an un-prefetched s_load at the head of every layer was a quarter of the sweep time). Small records are
@@ -391,13 +394,13 @@ __global__ __launch_bounds__(kThreads) void ldpc_layered_kernel(
             if (block >= kM) {
                 // regular layer: all 360 checks at once
                 if (work) {
-                    const int jj = tid;
+                    const int jj = row;
                     uint32_t mw[MW], nm[MW];
 #pragma unroll
                     for (int w = 0; w < MW; w++) mw[w] = pre[w];
                     if (i + 1 < q) {
 #pragma unroll
-                        for (int w = 0; w < MW; w++) pre[w] = mp[(MW + w) * kMsgStride + tid];
+                        for (int w = 0; w < MW; w++) pre[w] = mp[(MW + w) * kMsgStride + row];
                     }
                     DVBS2_DEG_SWITCH
 #pragma unroll
@@ -407,13 +410,13 @@ __global__ __launch_bounds__(kThreads) void ldpc_layered_kernel(
             } else {
                 if (nc != kHazardWalk) {
                     // sequential-order hazard inside the layer: check_node_hazard (every thread takes every barrier)
-                    const int jj = tid;
+                    const int jj = row;
                     uint32_t mw[MW], nm[MW];
 #pragma unroll
                     for (int w = 0; w < MW; w++) mw[w] = work ? pre[w] : 0x80808080u;
                     if (work && i + 1 < q) {
 #pragma unroll
-                        for (int w = 0; w < MW; w++) pre[w] = mp[(MW + w) * kMsgStride + tid];
+                        for (int w = 0; w < MW; w++) pre[w] = mp[(MW + w) * kMsgStride + row];
                     }
                     DVBS2_HAZ_SWITCH
                     if (work) {
@@ -440,7 +443,7 @@ __global__ __launch_bounds__(kThreads) void ldpc_layered_kernel(
                     __syncthreads();
                     if (work && i + 1 < q) {
 #pragma unroll
-                        for (int w = 0; w < MW; w++) pre[w] = mp[(MW + w) * kMsgStride + tid];
+                        for (int w = 0; w < MW; w++) pre[w] = mp[(MW + w) * kMsgStride + row];
                     }
                 }
                 TSTAMP(tC); tm_conf += tC - tB;
