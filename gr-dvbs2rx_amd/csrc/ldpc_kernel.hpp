@@ -29,6 +29,31 @@ __host__ __device__ constexpr size_t half_lds_bytes(int N) { return ((size_t)N +
 
 __device__ __forceinline__ int wrap360(int t) { return t >= kM ? t - kM : t; }
 
+// Pinned instruction selection for the two spots where the compiler's canonical form costs more issue slots.
+// clamp(a + b + 128, 0, 255) as v_add3_u32 + v_med3_i32 (the compiler emits add, max, add, min).
+__device__ __forceinline__ int sat_sum_u8(int a, int b)
+{
+    int t, r;
+    asm("v_add3_u32 %0, %1, %2, %3" : "=v"(t) : "v"(a), "v"(b), "s"(128));
+    asm("v_med3_i32 %0, %1, 0, %2" : "=v"(r) : "v"(t), "s"(255));
+    return r;
+}
+// R2: mag = clamp(|Lb - mb| - 1, 0, 126) as v_sad_u16 + v_med3_i32 (the compiler splits the clamp into max + min)
+__device__ __forceinline__ int mag_offset(int Lb, int mb)
+{
+    int r;
+    const int a = (int)__builtin_amdgcn_sad_u16((uint32_t)Lb, (uint32_t)mb, 0xffffffffu);
+    asm("v_med3_i32 %0, %1, 0, %2" : "=v"(r) : "v"(a), "s"(126));
+    return r;
+}
+// low bytes of four 32-bit values -> one dword (two v_perm_b32 + or)
+__device__ __forceinline__ uint32_t pack4_lo8(int a, int b, int c, int d)
+{
+    const uint32_t lo = __builtin_amdgcn_perm((uint32_t)b, (uint32_t)a, 0x0c0c0400u); // a.b0 | b.b0 << 8
+    const uint32_t hi = __builtin_amdgcn_perm((uint32_t)d, (uint32_t)c, 0x04000c0cu); // c.b0 << 16 | d.b0 << 24
+    return lo | hi;
+}
+
 // One check node (layered_decoder.hh:56-77 + algorithms.hh:170-192,203-206), fully unrolled for its degree.
 // LLRs are offset-binary bytes Lb = L + 128 in LDS; messages are offset-binary bytes, 4 per dword.
 // The kernel is VALU-issue bound (not HBM bound): ~22 VALU + 2 LDS instructions per edge.
@@ -56,8 +81,7 @@ __device__ __forceinline__ void check_node(uint8_t* __restrict__ lds, const uint
         const int mb = (int)((mw[k >> 2] >> (8 * (k & 3))) & 0xffu);
         // R1 inp = sat8(L - m); R2 mag = usat(qabs(inp) - 1) == med3(|L - m| - 1, 0, 126)
         int d = min(max(Lb[k] - mb, -128), 127);
-        int mag = (int)__builtin_amdgcn_sad_u16((uint32_t)Lb[k], (uint32_t)mb, 0xffffffffu);
-        mag = min(max(mag, 0), 126);
+        int mag = mag_offset(Lb[k], mb);
         if (LAYER0 && k == DEG - 1) { d = last_valid ? d : 0; mag = last_valid ? mag : 127; }
         inp[k] = d; mg[k] = mag;
         // R3 two smallest magnitudes (new min1 = median(min0, min1, mag)); R4 xor of the sign bits
@@ -65,9 +89,10 @@ __device__ __forceinline__ void check_node(uint8_t* __restrict__ lds, const uint
         min0 = min(min0, mag);
         signs ^= d;
     }
-#pragma unroll
-    for (int w = 0; w < (DEG + 3) / 4; w++) nm[w] = 0;
     const int s01 = min0 + min1;
+    int msgc[4 * ((DEG + 3) / 4)];
+#pragma unroll
+    for (int k = 0; k < 4 * ((DEG + 3) / 4); k++) msgc[k] = 0;
 #pragma unroll
     for (int k = 0; k < DEG; k++) {
         // R5 out = vsign(mag == min0 ? min1 : min0, (signs ^ x) | 127); mag is min0 or >= min1, so the selected
@@ -76,11 +101,14 @@ __device__ __forceinline__ void check_node(uint8_t* __restrict__ lds, const uint
         const int sg = (signs ^ inp[k]) >> 31;
         const int out = (other ^ sg) - sg;
         // R6 LLR = sat8(inp + out) with the unclamped out; R7 stored message = clamp(out, -32, 31)
-        const int nl = min(max(inp[k] + out + 128, 0), 255);
+        const int nl = sat_sum_u8(inp[k], out);
         if (!(LAYER0 && k == DEG - 1) || last_valid) lds[ad[k]] = (uint8_t)nl;
-        const int nmsg = min(max(out, -32), 31) + 128;
-        nm[k >> 2] |= (uint32_t)nmsg << (8 * (k & 3));
+        msgc[k] = min(max(out, -32), 31);
     }
+    // two's-complement low bytes ^ 0x80 = offset binary
+#pragma unroll
+    for (int w = 0; w < (DEG + 3) / 4; w++)
+        nm[w] = pack4_lo8(msgc[4 * w], msgc[4 * w + 1], msgc[4 * w + 2], msgc[4 * w + 3]) ^ 0x80808080u;
 }
 
 // Hazard layer (two or more entries of one group, ldpc_schedule.h): the reference's strictly ordered update
@@ -116,8 +144,7 @@ __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, con
                 const int Lb = lds[ad[k]];
                 const int mb = (int)((mw[k >> 2] >> (8 * (k & 3))) & 0xffu);
                 int d = min(max(Lb - mb, -128), 127);
-                int mag = (int)__builtin_amdgcn_sad_u16((uint32_t)Lb, (uint32_t)mb, 0xffffffffu);
-                mag = min(max(mag, 0), 126);
+                int mag = mag_offset(Lb, mb);
                 if (LAYER0 && k == DEG - 1) { d = last_valid ? d : 0; mag = last_valid ? mag : 127; }
                 inp[k] = d; mg[k] = mag;
                 min1 = min(max(mag, min0), min1);
@@ -137,8 +164,7 @@ __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, con
             for (int k = 0; k < NC; k++) {
                 const int mb = (int)((mw[k >> 2] >> (8 * (k & 3))) & 0xffu);
                 const int d = min(max(Lh[k] - mb, -128), 127);
-                int mag = (int)__builtin_amdgcn_sad_u16((uint32_t)Lh[k], (uint32_t)mb, 0xffffffffu);
-                mag = min(max(mag, 0), 126);
+                const int mag = mag_offset(Lh[k], mb);
                 inp[k] = d; mg[k] = mag;
                 min1 = min(max(mag, min0), min1);
                 min0 = min(min0, mag);
@@ -149,7 +175,7 @@ __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, con
                 const int other = (mg[k] == min0) ? min1 : min0;
                 const int sg = (signs ^ inp[k]) >> 31;
                 const int out = (other ^ sg) - sg;
-                lds[ad[k]] = (uint8_t)min(max(inp[k] + out + 128, 0), 255);
+                lds[ad[k]] = (uint8_t)sat_sum_u8(inp[k], out);
                 nm[k >> 2] |= (uint32_t)(min(max(out, -32), 31) + 128) << (8 * (k & 3));
             }
         }
@@ -158,14 +184,15 @@ __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, con
         if ((start >> 6) != ((start + 2 * block - 1) >> 6)) __syncthreads();
     }
     __syncthreads();
+    const int s01 = min0 + min1;
     if (work) {
 #pragma unroll
         for (int k = 0; k < DEG; k++) {
             if (k >= NC) {
-                const int other = (mg[k] == min0) ? min1 : min0;
+                const int other = s01 - min(mg[k], min1);
                 const int sg = (signs ^ inp[k]) >> 31;
                 const int out = (other ^ sg) - sg;
-                const int nl = min(max(inp[k] + out + 128, 0), 255);
+                const int nl = sat_sum_u8(inp[k], out);
                 if (!(LAYER0 && k == DEG - 1) || last_valid) lds[ad[k]] = (uint8_t)nl;
                 nm[k >> 2] |= (uint32_t)(min(max(out, -32), 31) + 128) << (8 * (k & 3));
             }
