@@ -155,28 +155,39 @@ __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, con
     }
 #pragma unroll
     for (int w = 0; w < (DEG + 3) / 4; w++) nm[w] = 0;
+    // P2 keeps only what the NEXT block needs on its critical path: the new hazard LLRs. For hazard entry k the
+    // magnitude sent back is the minimum over all OTHER entries = min(partial min0 of the regular entries, the
+    // other hazard magnitudes) and the sign is the xor of all other signs; the merge of the hazard entries into
+    // (min0, min1, signs) for P3 and the hazard message bytes are computed after the loop.
+    int hout[NC];
+#pragma unroll
+    for (int k = 0; k < NC; k++) { hout[k] = 0; inp[k] = 0; mg[k] = 127; }
     for (int start = 0; start < kM; start += block) {
         if (work && jj >= start && jj < start + block) {
             int Lh[NC];
 #pragma unroll
             for (int k = 0; k < NC; k++) Lh[k] = lds[ad[k]];
+            int xall = signs;
 #pragma unroll
             for (int k = 0; k < NC; k++) {
                 const int mb = (int)((mw[k >> 2] >> (8 * (k & 3))) & 0xffu);
-                const int d = min(max(Lh[k] - mb, -128), 127);
-                const int mag = mag_offset(Lh[k], mb);
-                inp[k] = d; mg[k] = mag;
-                min1 = min(max(mag, min0), min1);
-                min0 = min(min0, mag);
-                signs ^= d;
+                inp[k] = min(max(Lh[k] - mb, -128), 127);
+                mg[k] = mag_offset(Lh[k], mb);
+                xall ^= inp[k];
             }
+            int pre[NC + 1], suf[NC + 1]; // pre[k] = min(min0, mg[0..k)), suf[k] = min(mg[k..NC))
+            pre[0] = min0; suf[NC] = 127;
+#pragma unroll
+            for (int k = 0; k < NC; k++) pre[k + 1] = min(pre[k], mg[k]);
+#pragma unroll
+            for (int k = NC - 1; k >= 0; k--) suf[k] = min(suf[k + 1], mg[k]);
 #pragma unroll
             for (int k = 0; k < NC; k++) {
-                const int other = (mg[k] == min0) ? min1 : min0;
-                const int sg = (signs ^ inp[k]) >> 31;
+                const int other = min(pre[k], suf[k + 1]);
+                const int sg = (xall ^ inp[k]) >> 31;
                 const int out = (other ^ sg) - sg;
+                hout[k] = out;
                 lds[ad[k]] = (uint8_t)sat_sum_u8(inp[k], out);
-                nm[k >> 2] |= (uint32_t)(min(max(out, -32), 31) + 128) << (8 * (k & 3));
             }
         }
         // the next block reads what this one wrote: a workgroup barrier, unless both blocks sit inside one and the
@@ -184,6 +195,13 @@ __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, con
         if ((start >> 6) != ((start + 2 * block - 1) >> 6)) __syncthreads();
     }
     __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NC; k++) {
+        min1 = min(max(mg[k], min0), min1);
+        min0 = min(min0, mg[k]);
+        signs ^= inp[k];
+        nm[k >> 2] |= (uint32_t)(min(max(hout[k], -32), 31) + 128) << (8 * (k & 3));
+    }
     const int s01 = min0 + min1;
     if (work) {
 #pragma unroll
