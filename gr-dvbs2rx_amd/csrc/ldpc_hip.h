@@ -47,6 +47,7 @@ private:
     int dmax_ = 0;            // kernel variant: handles check degrees dmax-7 .. dmax (8, 12, ..., 32)
     uint32_t* d_recs_ = nullptr;  // per-layer records (ldpc_hip.hip)
     size_t lds_bytes_ = 0;
+    bool pr_ = false;             // parity-in-records kernel variant selected (ldpc_kernel_pr.hpp)
     unsigned long long* d_tdbg_ = nullptr; // DVBS2_TIMING=1: per-wave cycle-counter breakdown (diagnostics)
     uint8_t* d_state_ = nullptr;  // max_frames * N, internal layout, offset-binary LLRs
     uint32_t* d_msgs_ = nullptr;  // max_frames * q * words_per_check * 384

@@ -17,6 +17,7 @@
 //     ordered update) are processed in ascending lane blocks of B_i (ldpc_schedule.h).
 #include "ldpc_hip.h"
 #include "ldpc_kernel.hpp"
+#include "ldpc_kernel_pr.hpp"
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -102,6 +103,19 @@ LdpcDecoderHip::LdpcDecoderHip(const LdpcTableDesc* table, int out_bits_message,
             hr[(size_t)i * RS + 5 + 2 * k] = 360u - e.rot;
         }
     }
+    // "parity in records" variant (ldpc_kernel_pr.hpp): check degree <= 7, at most 4 hazard entries per layer, and two
+    // pair workgroups must fit the 160 KB of LDS
+    pr_ = dmax_ == 8 && degmax <= 7 && getenv("DVBS2_PR") != nullptr; // opt-in: measured +3 % on table B4, -25 % on B1
+    for (const LdpcLayer& L : sched_.layers)
+        if (L.block < 360 && (L.n_conflict > 4 || (L.n_conflict > 2 ? 4 : 2) > L.cnt)) pr_ = false;
+    if (2 * pr_lds_bytes(sched_.N, sched_.K) > 160 * 1024) pr_ = false;
+    if (pr_) {
+        const int q = sched_.q;
+        hr[(size_t)(q - 1) * RS + 4 + 2 * sched_.layers[q - 1].cnt] = (uint32_t)sched_.K;          // own parity of the last layer: row q-1 at offset K
+        hr[(size_t)(q - 1) * RS + 5 + 2 * sched_.layers[q - 1].cnt] = 360u;
+        hr[(size_t)0 * RS + 4 + 2 * (sched_.layers[0].cnt + 1)] = (uint32_t)sched_.K + 359u;     // previous parity of layer 0: same row, one lane down
+        hr[(size_t)0 * RS + 5 + 2 * (sched_.layers[0].cnt + 1)] = 1u;
+    }
     HIP_OK(hipMalloc(&d_recs_, hr.size() * 4));
     HIP_OK(hipMemcpy(d_recs_, hr.data(), hr.size() * 4, hipMemcpyHostToDevice));
     HIP_OK(hipMalloc(&d_state_, (size_t)max_frames_ * sched_.N));
@@ -114,8 +128,10 @@ LdpcDecoderHip::LdpcDecoderHip(const LdpcTableDesc* table, int out_bits_message,
     HIP_OK(hipEventCreate(&ev0_));
     HIP_OK(hipEventCreate(&ev1_));
     if (getenv("DVBS2_TIMING")) { HIP_OK(hipMalloc(&d_tdbg_, (size_t)max_frames_ * 6 * 8 * 8)); HIP_OK(hipMemset(d_tdbg_, 0, (size_t)max_frames_ * 6 * 8 * 8)); }
-    lds_bytes_ = 2 * half_lds_bytes(sched_.N);
-    switch (dmax_) {
+    lds_bytes_ = pr_ ? pr_lds_bytes(sched_.N, sched_.K) : 2 * half_lds_bytes(sched_.N);
+    if (const char* e = getenv("DVBS2_LDS_PAD")) lds_bytes_ += (size_t)atoi(e); // occupancy experiments only
+    if (pr_) HIP_OK(ldpc_pr_prepare(lds_bytes_));
+    else switch (dmax_) {
         case 8: HIP_OK(ldpc_variant_prepare<8>(lds_bytes_)); break;   case 12: HIP_OK(ldpc_variant_prepare<12>(lds_bytes_)); break;
         case 16: HIP_OK(ldpc_variant_prepare<16>(lds_bytes_)); break; case 20: HIP_OK(ldpc_variant_prepare<20>(lds_bytes_)); break;
         case 24: HIP_OK(ldpc_variant_prepare<24>(lds_bytes_)); break; case 28: HIP_OK(ldpc_variant_prepare<28>(lds_bytes_)); break;
@@ -148,7 +164,8 @@ int LdpcDecoderHip::decode_device(const int8_t* d_llr_in, int n_frames, int max_
         la.recs = d_recs_; la.llr_in = in; la.state = d_state_; la.msgs = d_msgs_; la.iters = d_iters_; la.good = d_good_; la.target = target;
         la.n_frames = n_frames; la.N = sched_.N; la.K = sched_.K; la.q = sched_.q; la.cap = max_trials; la.stop_on_good = stop_on_good;
         la.tdbg = d_tdbg_; la.lds_bytes = lds_bytes; la.stream = stream;
-        switch (dmax_) {
+        if (pr_) ldpc_pr_launch(la);
+        else switch (dmax_) {
             case 8: ldpc_variant_launch<8>(la); break;   case 12: ldpc_variant_launch<12>(la); break;
             case 16: ldpc_variant_launch<16>(la); break; case 20: ldpc_variant_launch<20>(la); break;
             case 24: ldpc_variant_launch<24>(la); break; case 28: ldpc_variant_launch<28>(la); break;
@@ -162,7 +179,7 @@ int LdpcDecoderHip::decode_device(const int8_t* d_llr_in, int n_frames, int max_
         }
     };
     // bnl = 0 before the first update (layered_decoder.hh:27-31,149): offset-binary zero bytes
-    HIP_RET(hipMemsetAsync(d_msgs_, 0x80, (size_t)n_frames * sched_.q * words_per_check_ * kMsgStride * 4, stream));
+    if (!pr_) HIP_RET(hipMemsetAsync(d_msgs_, 0x80, (size_t)n_frames * sched_.q * words_per_check_ * kMsgStride * 4, stream));
     launch(d_llr_in, nullptr, 1);
     HIP_RET(hipGetLastError());
     if (d_tdbg_) {

@@ -57,10 +57,20 @@ __device__ __forceinline__ uint32_t pack4_lo8(int a, int b, int c, int d)
 // One check node (layered_decoder.hh:56-77 + algorithms.hh:170-192,203-206), fully unrolled for its degree.
 // LLRs are offset-binary bytes Lb = L + 128 in LDS; messages are offset-binary bytes, 4 per dword.
 // The kernel is VALU-issue bound (not HBM bound): ~22 VALU + 2 LDS instructions per edge.
-template <int DEG, bool LAYER0>
+//
+// Parity links. Classic layout (PR = false): both parity LLRs live in LDS like the data LLRs. "Parity in records"
+// (PR = true, low-rate tables, see ldpc_kernel_pr.hpp): parity row i is only ever touched by thread j of layers i and
+// i+1, so it never needs LDS -- the own-parity LLR arrives in `own_in` (byte 7 of the NEXT layer's message
+// record, where layer i+1 left it in the previous sweep), the previous-parity LLR is `carry` (what this thread's
+// own-parity link produced one layer ago), the new own-parity LLR becomes the carry and the new previous-parity
+// LLR is returned in byte 7 of this layer's record. Only row q-1 (own parity of the LAST layer, previous
+// parity of layer 0 shifted by one lane) stays in LDS.
+template <int DEG, bool LAYER0, bool PR = false, bool LAST = false>
 __device__ __forceinline__ void check_node(uint8_t* __restrict__ lds, const uint32_t* ent /*uniform: S0, thr pairs*/,
-                                           int jj, const uint32_t* mw, uint32_t* nm)
+                                           int jj, const uint32_t* mw, uint32_t* nm, int own_in = 0, int* carry = nullptr)
 {
+    constexpr bool OWN_REG = PR && !LAST;     // entry DEG-2
+    constexpr bool PREV_REG = PR && !LAYER0;  // entry DEG-1
     int ad[DEG], Lb[DEG];
 #pragma unroll
     for (int k = 0; k < DEG; k++) {
@@ -70,9 +80,14 @@ __device__ __forceinline__ void check_node(uint8_t* __restrict__ lds, const uint
         else ad[k] = jj + (int)ent[2 * k] - ((uint32_t)jj < ent[2 * k + 1] ? 0 : kM);
     }
 #pragma unroll
-    for (int k = 0; k < DEG; k++) Lb[k] = lds[ad[k]];
+    for (int k = 0; k < DEG; k++) {
+        if (OWN_REG && k == DEG - 2) Lb[k] = own_in;
+        else if (PREV_REG && k == DEG - 1) Lb[k] = *carry;
+        else Lb[k] = lds[ad[k]];
+    }
     // check (0,0) has no previous-parity link (layered_decoder.hh:56,63-66)
     const bool last_valid = !LAYER0 || jj != 0;
+    int spare = 0x80;
 
     int inp[DEG], mg[DEG];
     int min0 = 127, min1 = 127, signs = 0;
@@ -102,13 +117,19 @@ __device__ __forceinline__ void check_node(uint8_t* __restrict__ lds, const uint
         const int out = (other ^ sg) - sg;
         // R6 LLR = sat8(inp + out) with the unclamped out; R7 stored message = clamp(out, -32, 31)
         const int nl = sat_sum_u8(inp[k], out);
-        if (!(LAYER0 && k == DEG - 1) || last_valid) lds[ad[k]] = (uint8_t)nl;
+        if (OWN_REG && k == DEG - 2) *carry = nl;
+        else if (PREV_REG && k == DEG - 1) spare = nl;
+        else if (!(LAYER0 && k == DEG - 1) || last_valid) lds[ad[k]] = (uint8_t)nl;
         msgc[k] = min(max(out, -32), 31);
     }
     // two's-complement low bytes ^ 0x80 = offset binary
 #pragma unroll
     for (int w = 0; w < (DEG + 3) / 4; w++)
         nm[w] = pack4_lo8(msgc[4 * w], msgc[4 * w + 1], msgc[4 * w + 2], msgc[4 * w + 3]) ^ 0x80808080u;
+    if (PR) { // byte 7 of the record carries the previous-parity LLR (DEG <= 7)
+        const uint32_t w1 = ((DEG + 3) / 4 > 1) ? nm[1] : 0x80808080u;
+        nm[1] = (w1 & 0x00ffffffu) | ((uint32_t)spare << 24);
+    }
 }
 
 // Hazard layer (two or more entries of one group, ldpc_schedule.h): the reference's strictly ordered update
@@ -125,12 +146,15 @@ __device__ __forceinline__ void check_node(uint8_t* __restrict__ lds, const uint
 // (moving a regular entry into the ordered part does not change the result).
 constexpr int kMaxHazard = 8;
 constexpr int kHazardWalk = 15; // header code: too many hazard entries, fall back to the single-wave chunk walk
-template <int DEG, int NC, bool LAYER0>
+template <int DEG, int NC, bool LAYER0, bool PR = false, bool LAST = false>
 __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, const uint32_t* ent, int jj, bool work,
-                                                  int block, const uint32_t* mw, uint32_t* nm)
+                                                  int block, const uint32_t* mw, uint32_t* nm, int own_in = 0, int* carry = nullptr)
 {
+    constexpr bool OWN_REG = PR && !LAST;     // entry DEG-2 (see check_node)
+    constexpr bool PREV_REG = PR && !LAYER0;  // entry DEG-1
     int ad[DEG], inp[DEG], mg[DEG];
     int min0 = 127, min1 = 127, signs = 0;
+    int spare = 0x80;
     const bool last_valid = !LAYER0 || jj != 0;
     if (work) {
 #pragma unroll
@@ -141,7 +165,7 @@ __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, con
 #pragma unroll
         for (int k = 0; k < DEG; k++) {
             if (k >= NC) { // regular entry
-                const int Lb = lds[ad[k]];
+                const int Lb = (OWN_REG && k == DEG - 2) ? own_in : (PREV_REG && k == DEG - 1) ? *carry : (int)lds[ad[k]];
                 const int mb = (int)((mw[k >> 2] >> (8 * (k & 3))) & 0xffu);
                 int d = min(max(Lb - mb, -128), 127);
                 int mag = mag_offset(Lb, mb);
@@ -159,6 +183,7 @@ __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, con
     // magnitude sent back is the minimum over all OTHER entries = min(partial min0 of the regular entries, the
     // other hazard magnitudes) and the sign is the xor of all other signs; the merge of the hazard entries into
     // (min0, min1, signs) for P3 and the hazard message bytes are computed after the loop.
+    if (PR && (DEG + 3) / 4 < 2) nm[1] = 0;
     int hout[NC];
 #pragma unroll
     for (int k = 0; k < NC; k++) { hout[k] = 0; inp[k] = 0; mg[k] = 127; }
@@ -211,10 +236,13 @@ __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, con
                 const int sg = (signs ^ inp[k]) >> 31;
                 const int out = (other ^ sg) - sg;
                 const int nl = sat_sum_u8(inp[k], out);
-                if (!(LAYER0 && k == DEG - 1) || last_valid) lds[ad[k]] = (uint8_t)nl;
+                if (OWN_REG && k == DEG - 2) *carry = nl;
+                else if (PREV_REG && k == DEG - 1) spare = nl;
+                else if (!(LAYER0 && k == DEG - 1) || last_valid) lds[ad[k]] = (uint8_t)nl;
                 nm[k >> 2] |= (uint32_t)(min(max(out, -32), 31) + 128) << (8 * (k & 3));
             }
         }
+        if (PR) nm[1] = (nm[1] & 0x00ffffffu) | ((uint32_t)spare << 24);
     }
 }
 

@@ -1,0 +1,281 @@
+// ldpc_kernel_pr.hpp -- "parity in records" variant of the layered LDPC kernel for low-rate normal frames.
+//
+// Why: a frame running alone on a CU is latency bound (about 250 in-order instructions per wave per layer plus an
+// LDS round trip and a barrier): one pair of frames takes 1.36x the time of one frame, and going from one pair
+// to two pairs per CU gained 1.45-1.5x on short frames. What limits normal frames to one pair per CU is LDS:
+// 64800 LLR bytes per frame. But parity row i is only ever touched by thread j of layers i and i+1 (own parity,
+// then previous parity), so it can live in registers between those two layers and in byte 7 of the per-thread
+// message record in between sweeps (ldpc_kernel.hpp, check_node<.., PR>). LDS then holds K + 360 bytes per frame
+// (information LLRs + parity row q-1) and, for K <= 32400 (rates up to 1/2) with check degree <= 7, TWO pair
+// workgroups fit a CU: 24 waves, 6 per SIMD, at 80 VGPRs.
+//
+// Layout per workgroup: [half 0 LLRs][half 1 LLRs][sign vectors, shared by the halves][flags 0][flags 1].
+// Message record of (layer i, row j): 2 dwords = message bytes 0..deg-1, byte 7 = parity LLR P[i-1][j] as left by
+// layer i (offset binary); record 0 byte 7 is unused.
+#pragma once
+#include "ldpc_kernel.hpp"
+#include <cstdio>
+#include <cstdlib>
+
+namespace dvbs2 {
+
+__host__ __device__ constexpr size_t pr_half_bytes(int K) { return ((size_t)K + kM + 15) / 16 * 16; }
+__host__ __device__ constexpr size_t pr_lds_bytes(int N, int K) { return 2 * pr_half_bytes(K) + (size_t)(N / kM) * kSvWords * 4 + 64; }
+
+#ifdef DVBS2_LDPC_INSTANTIATE_PR
+#define DVBS2_PR_CASE(D) case D: { \
+        if (first_layer) check_node<D, true, true, false>(lds, ent, jj, mw, nm, own_in, &carry); \
+        else if (last_layer) check_node<D, false, true, true>(lds, ent, jj, mw, nm, own_in, &carry); \
+        else check_node<D, false, true, false>(lds, ent, jj, mw, nm, own_in, &carry); } break;
+#define DVBS2_PR_SWITCH switch (deg) { DVBS2_PR_CASE(3) DVBS2_PR_CASE(4) DVBS2_PR_CASE(5) DVBS2_PR_CASE(6) DVBS2_PR_CASE(7) default: break; }
+#define DVBS2_PRH_CALL(D, NCV) { if constexpr (D - 2 >= NCV) { \
+        if (first_layer) check_node_hazard<D, NCV, true, true, false>(lds, ent, jj, work, block, mw, nm, own_in, &carry); \
+        else if (last_layer) check_node_hazard<D, NCV, false, true, true>(lds, ent, jj, work, block, mw, nm, own_in, &carry); \
+        else check_node_hazard<D, NCV, false, true, false>(lds, ent, jj, work, block, mw, nm, own_in, &carry); } }
+#define DVBS2_PRH_CASE(D) case D: { if (nc == 2) DVBS2_PRH_CALL(D, 2) else if (nc == 4) DVBS2_PRH_CALL(D, 4) } break;
+#define DVBS2_PRH_SWITCH switch (deg) { DVBS2_PRH_CASE(4) DVBS2_PRH_CASE(5) DVBS2_PRH_CASE(6) DVBS2_PRH_CASE(7) default: break; }
+
+// Records use the PR LDS layout: data entries as in the classic kernel; own parity of the last layer at K + j;
+// previous parity of layer 0 at K + (j + 359) mod 360 (S0 = K + 359, thr = 1).
+__global__ __launch_bounds__(kThreads, 6) void ldpc_layered_pr_kernel(
+    const uint32_t* __restrict__ recs, const int8_t* __restrict__ llr_in, uint8_t* __restrict__ state,
+    uint32_t* __restrict__ msgs, int* __restrict__ iters, int* __restrict__ good, const int* __restrict__ target,
+    int n_frames, int N, int K, int q, int cap, int stop_on_good)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_all[];
+    constexpr int DMAX = 8, RS = rec_stride(DMAX), MW = 2;
+    const int half = __builtin_amdgcn_readfirstlane(threadIdx.x >= kHalf ? 1 : 0);
+    const int tid = threadIdx.x - half * kHalf;
+    uint8_t* lds = lds_all + half * pr_half_bytes(K);
+    uint32_t* sv = reinterpret_cast<uint32_t*>(lds_all + 2 * pr_half_bytes(K));
+    volatile int* flags_all = reinterpret_cast<volatile int*>(sv + (N / kM) * kSvWords);
+    volatile int* flags = flags_all + 8 * half;        // [0] bad-or, [1] finished, [2] pre-test failed, [3] full test needed
+    volatile int* other_flags = flags_all + 8 * (1 - half);
+    const int f = 2 * blockIdx.x + half;
+    const bool have_frame = f < n_frames;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int NGD = K / kM, NG = N / kM;
+    const bool active = tid < kM;
+    const int row = tid < kM ? tid : kM - 1; // threads 360..383 mirror row 359 (ldpc_kernel.hpp)
+
+    uint32_t* msg_base = msgs + (size_t)(have_frame ? f : 0) * q * MW * kMsgStride;
+    int it = 0, tgt = 0;
+    bool finished = !have_frame;
+    if (have_frame) {
+        tgt = target ? target[f] : cap;
+        if (llr_in) {
+            const int8_t* src = llr_in + (size_t)f * N;
+            const uint2* src8 = reinterpret_cast<const uint2*>(src);
+            for (int c = tid; c < K / 8; c += kHalf) {
+                uint2 v = src8[c];
+                v.x ^= 0x80808080u; v.y ^= 0x80808080u;
+                *reinterpret_cast<uint2*>(lds + 8 * c) = v;
+            }
+            if (active) {
+                // parity[q*j + i] = P[i][j] (layered_decoder.hh:150-152): row q-1 to LDS, row i < q-1 to byte 7 of
+                // record i+1; all message bytes start at offset-binary zero (bnl = 0, layered_decoder.hh:27-31)
+                const int8_t* pj = src + K + (size_t)q * tid;
+                msg_base[0 * kMsgStride + tid] = 0x80808080u;
+                msg_base[1 * kMsgStride + tid] = 0x80808080u;
+                for (int i = 0; i < q - 1; i++) {
+                    const uint32_t b = (uint8_t)pj[i] ^ 0x80u;
+                    msg_base[((i + 1) * MW + 0) * kMsgStride + tid] = 0x80808080u;
+                    msg_base[((i + 1) * MW + 1) * kMsgStride + tid] = 0x00808080u | (b << 24);
+                }
+                lds[K + tid] = (uint8_t)pj[q - 1] ^ 0x80u;
+            }
+        } else {
+            it = iters[f];
+            if (it >= tgt) finished = true;
+            else {
+                // resume: information LLRs and parity row q-1 come back from the state buffer; the other parity rows
+                // are still in the message records
+                const uint2* src8 = reinterpret_cast<const uint2*>(state + (size_t)f * N);
+                for (int c = tid; c < K / 8; c += kHalf) *reinterpret_cast<uint2*>(lds + 8 * c) = src8[c];
+                if (active) lds[K + tid] = state[(size_t)f * N + K + kM * (q - 1) + tid];
+            }
+        }
+    }
+    const bool untouched = finished;
+    if (tid == 0) { flags[0] = 0; flags[2] = 0; flags[3] = 0; flags[1] = finished ? 1 : 0; }
+    __syncthreads();
+
+    bool is_good = false;
+    for (;;) {
+        // ---- syndrome test: pre-test on one layer, full test only for frames that pass it (see ldpc_kernel.hpp) ----
+        const bool need_synd = !finished && (stop_on_good || it >= tgt);
+        if (need_synd && active) {
+            const int i0 = it % q;
+            const uint32_t* rec = recs + (size_t)i0 * RS;
+            const int deg = (int)(rec[0] & 0xffu) + 2;
+            uint32_t x = 0, z = 0;
+            for (int k = 0; k < deg; k++) {
+                uint32_t v;
+                if (k == deg - 2 && i0 != q - 1) v = msg_base[((i0 + 1) * MW + 1) * kMsgStride + tid] >> 24;       // own parity P[i0]
+                else if (k == deg - 1 && i0 != 0) v = msg_base[(i0 * MW + 1) * kMsgStride + tid] >> 24;           // previous parity P[i0-1]
+                else {
+                    const int a0 = tid + (int)rec[4 + 2 * k] - ((uint32_t)tid < rec[5 + 2 * k] ? 0 : kM);
+                    v = lds[a0];
+                    if (i0 == 0 && k == deg - 1 && tid == 0) v = 0x81u; // check (0,0) has no previous parity
+                }
+                x ^= v;
+                z |= (v == 0x80u);
+            }
+            const int bad_pre = (int)((((x >> 7) ^ (uint32_t)deg) & 1u) | z);
+            if (__ballot(bad_pre) != 0 && lane == 0) flags[2] = 1;
+        }
+        __syncthreads();
+        const bool need_full = need_synd && flags[2] == 0;
+        if (tid == 0) flags[3] = need_full ? 1 : 0;
+        __syncthreads();
+        if (flags[3] != 0 || other_flags[3] != 0) { // uniform over the workgroup
+            // the sign-vector buffer is shared: the halves take turns
+            for (int h = 0; h < 2; h++) {
+                const bool mine = need_full && half == h;
+                if (mine) {
+                    unsigned long long zero_any = 0;
+                    for (int g = 0; g < NG; g++) {
+                        uint32_t v = 0xffu;
+                        if (active) {
+                            if (g < NGD) v = lds[kM * g + tid];
+                            else if (g == NG - 1) v = lds[K + tid];
+                            else v = msg_base[((g - NGD + 1) * MW + 1) * kMsgStride + tid] >> 24; // parity row g - NGD
+                        }
+                        const unsigned long long neg = __ballot(v < 0x80u);
+                        zero_any |= __ballot(v == 0x80u);
+                        if (lane == 0) *reinterpret_cast<uint2*>(&sv[g * kSvWords + 2 * wave]) = make_uint2((uint32_t)neg, (uint32_t)(neg >> 32));
+                    }
+                    if (zero_any != 0 && lane == 0) flags[0] = 1;
+                }
+                __syncthreads();
+                if (mine && tid < NG) {
+                    uint32_t* p = sv + tid * kSvWords;
+                    const uint32_t w0 = p[0], w1 = p[1];
+                    p[11] = (p[11] & 0xffu) | (w0 << 8);
+                    p[12] = (w0 >> 24) | (w1 << 8);
+                }
+                __syncthreads();
+                if (mine) {
+                    int bad = 0;
+                    for (int item = tid; item < q * 12; item += kHalf) {
+                        const int i = item / 12, w = item - 12 * i;
+                        const uint32_t* rec = recs + (size_t)i * RS;
+                        const int deg = (int)(rec[0] & 0xffu) + 2;
+                        uint32_t acc = 0;
+                        for (int k = 0; k < deg; k++) {
+                            int g, rot;
+                            if (k == deg - 2) { g = NGD + i; rot = 0; }                                   // own parity row i
+                            else if (k == deg - 1) { g = NGD + (i ? i - 1 : q - 1); rot = i ? 0 : 359; } // previous parity
+                            else { rot = kM - (int)rec[5 + 2 * k]; g = ((int)rec[4 + 2 * k] - rot) / kM; }
+                            const int t0 = wrap360(32 * w + rot);
+                            const uint32_t* p = sv + g * kSvWords + (t0 >> 5);
+                            uint32_t x = __funnelshift_r(p[0], p[1], t0 & 31);
+                            if (i == 0 && k == deg - 1 && w == 0) x &= ~1u;
+                            acc ^= x;
+                        }
+                        if (w == 11) acc &= 0xffu;
+                        bad |= acc != 0;
+                    }
+                    if (__ballot(bad) != 0 && lane == 0) flags[0] = 1;
+                }
+                __syncthreads();
+            }
+        }
+        if (need_synd) is_good = need_full && flags[0] == 0;
+        if (!finished && (it >= tgt || (stop_on_good && is_good))) finished = true;
+        __syncthreads();
+        if (tid == 0) { flags[0] = 0; flags[2] = 0; flags[1] = finished ? 1 : 0; }
+        __syncthreads();
+        if (finished && other_flags[1]) break;
+
+        // ---- one update sweep ----
+        const bool work = !finished;
+        uint32_t pre1[MW], pre2[MW]; // records of the next two layers for this row
+        int carry = 0x80;
+        if (work) {
+#pragma unroll
+            for (int w = 0; w < MW; w++) { pre1[w] = msg_base[w * kMsgStride + row]; pre2[w] = msg_base[(MW + w) * kMsgStride + row]; }
+        }
+        uint32_t nhdr = recs[0];
+        uint32_t nent[2 * DMAX];
+#pragma unroll
+        for (int k = 0; k < 2 * DMAX; k++) nent[k] = recs[4 + k];
+        for (int i = 0; i < q; i++) {
+            const uint32_t hdr = nhdr;
+            uint32_t ent[2 * DMAX];
+#pragma unroll
+            for (int k = 0; k < 2 * DMAX; k++) ent[k] = nent[k];
+            {
+                const uint32_t* nrec = recs + (size_t)(i + 1 < q ? i + 1 : 0) * RS;
+                nhdr = nrec[0];
+#pragma unroll
+                for (int k = 0; k < 2 * DMAX; k++) nent[k] = nrec[4 + k];
+            }
+            const int deg = (int)(hdr & 0xffu) + 2;
+            const int nc = (int)((hdr >> 8) & 0xfu);
+            const int block = (int)(hdr >> 16);
+            const bool first_layer = (i == 0), last_layer = (i == q - 1);
+            uint32_t* mp = msg_base + (size_t)i * MW * kMsgStride;
+            if (hdr & 0x8000u) __syncthreads();
+            const int jj = row;
+            uint32_t mw[MW], nm[MW];
+#pragma unroll
+            for (int w = 0; w < MW; w++) { mw[w] = work ? pre1[w] : 0x80808080u; pre1[w] = pre2[w]; }
+            const int own_in = (int)(pre1[1] >> 24); // byte 7 of record i+1 = P[i] (not used by the last layer)
+            if (work && i + 2 < q) {
+#pragma unroll
+                for (int w = 0; w < MW; w++) pre2[w] = mp[(2 * MW + w) * kMsgStride + row];
+            }
+            if (block >= kM) {
+                if (work) {
+                    DVBS2_PR_SWITCH
+#pragma unroll
+                    for (int w = 0; w < MW; w++) mp[w * kMsgStride + jj] = nm[w];
+                }
+            } else {
+                DVBS2_PRH_SWITCH
+                if (work) {
+#pragma unroll
+                    for (int w = 0; w < MW; w++) mp[w * kMsgStride + jj] = nm[w];
+                }
+            }
+        }
+        __syncthreads();
+        if (!finished) it++;
+    }
+
+    if (have_frame && !untouched) {
+        if (tid == 0) { iters[f] = it; good[f] = is_good ? 1 : 0; }
+        uint8_t* dst = state + (size_t)f * N;
+        for (int c = tid; c < K / 8; c += kHalf) reinterpret_cast<uint2*>(dst)[c] = *reinterpret_cast<const uint2*>(lds + 8 * c);
+        if (active) {
+            for (int i = 0; i < q - 1; i++) dst[K + kM * i + tid] = (uint8_t)(msg_base[((i + 1) * MW + 1) * kMsgStride + tid] >> 24);
+            dst[K + kM * (q - 1) + tid] = lds[K + tid];
+        }
+    }
+}
+
+#endif // DVBS2_LDPC_INSTANTIATE_PR
+
+hipError_t ldpc_pr_prepare(size_t lds_bytes);
+void ldpc_pr_launch(const LdpcLaunch& a);
+
+#ifdef DVBS2_LDPC_INSTANTIATE_PR
+hipError_t ldpc_pr_prepare(size_t lds_bytes)
+{
+    hipError_t e = hipFuncSetAttribute((const void*)ldpc_layered_pr_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e == hipSuccess && getenv("DVBS2_OCC")) {
+        int nb = -1;
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, ldpc_layered_pr_kernel, kThreads, lds_bytes);
+        fprintf(stderr, "[pr kernel] lds %zu bytes, occupancy API: %d workgroups per CU\n", lds_bytes, nb);
+    }
+    return e;
+}
+void ldpc_pr_launch(const LdpcLaunch& a)
+{
+    hipLaunchKernelGGL(ldpc_layered_pr_kernel, dim3((a.n_frames + 1) / 2), dim3(kThreads), a.lds_bytes, a.stream, a.recs, a.llr_in, a.state, a.msgs,
+                       a.iters, a.good, a.target, a.n_frames, a.N, a.K, a.q, a.cap, a.stop_on_good);
+}
+#endif
+
+} // namespace dvbs2

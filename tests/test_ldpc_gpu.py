@@ -159,3 +159,19 @@ def test_ragged_and_empty_batches():
         bits, out, ret = run_gpu(table, llr[:4], 4, trials)
         want, wret = T.oracle_ldpc_decode(table, llr[:4], 4, trials)
         assert ret.tolist() == wret and np.array_equal(out, want)
+
+
+def test_parity_in_records_variant(monkeypatch):
+    """The opt-in kernel variant that keeps parity LLRs in registers / message records (ldpc_kernel_pr.hpp) must give
+    the same bits: near-threshold groups (resume passes), never-converging input, hazard layers, layer 0 / last layer."""
+    monkeypatch.setenv("DVBS2_PR", "1")
+    for table, amp, sigma in (("S2_TABLE_B4", 6, 5.2), ("S2_TABLE_B1", 4, 6.6), ("S2_TABLE_B3", 5, 5.6)):
+        llr, _ = T.llr_codeword_awgn(table, 64, 99, amp=amp, sigma=sigma)
+        compare(table, llr, 32, 50)
+        compare(table, llr[:48], 16, 30)
+        # 33 frames: the last pair workgroup holds one frame and an idle half; its group is a group of one
+        bits, out, ret = run_gpu(table, llr[:33], 16, 30)
+        a, ra = T.oracle_ldpc_decode(table, llr[:32], 16, 30)
+        b, rb = T.oracle_ldpc_decode(table, llr[32:33], 1, 30)
+        assert ret.tolist() == ra + rb and np.array_equal(out, np.concatenate([a, b]))
+        compare(table, T.llr_noise(32, T.ldpc_info(table)[0], 5), 32, 4)
