@@ -411,7 +411,7 @@ int dvbs2_demap_estimate_snr_device(dvbs2_demap_t* h, const float* d_syms, int n
     if (!h) return fail(DVBS2_EINVAL, "null handle");
     if (n_frames < 0 || (n_frames && (!d_syms || !d_snr_lin))) return fail(DVBS2_EINVAL, "bad argument");
     if (n_frames > h->dm->max_frames()) return fail(DVBS2_ESIZE, "n_frames exceeds max_frames");
-    if (h->dm->snr_device(d_syms, n_frames, d_snr_lin, (hipStream_t)stream)) return fail(DVBS2_EDEVICE, h->dm->error());
+    if (h->dm->snr_device(d_syms, nullptr, n_frames, d_snr_lin, (hipStream_t)stream)) return fail(DVBS2_EDEVICE, h->dm->error());
     return DVBS2_OK;
     API_CATCH
 }
@@ -424,7 +424,34 @@ int dvbs2_demap_estimate_snr(dvbs2_demap_t* h, const float* syms, int n_frames, 
     if (n_frames > h->dm->max_frames()) return fail(DVBS2_ESIZE, "n_frames exceeds max_frames");
     if (n_frames == 0) return DVBS2_OK;
     if (int rc = demap_stage(h, syms, n_frames)) return rc;
-    if (h->dm->snr_device(h->d_syms, n_frames, h->d_snr, h->stream)) return fail(DVBS2_EDEVICE, h->dm->error());
+    if (h->dm->snr_device(h->d_syms, nullptr, n_frames, h->d_snr, h->stream)) return fail(DVBS2_EDEVICE, h->dm->error());
+    HCHK(hipMemcpyAsync(snr_lin, h->d_snr, (size_t)n_frames * 4, hipMemcpyDeviceToHost, h->stream));
+    HCHK(hipStreamSynchronize(h->stream));
+    return DVBS2_OK;
+    API_CATCH
+}
+
+int dvbs2_demap_refine_snr_device(dvbs2_demap_t* h, const float* d_syms, const int8_t* d_ref_llr, int n_frames, float* d_snr_lin, void* stream)
+{
+    API_TRY
+    if (!h) return fail(DVBS2_EINVAL, "null handle");
+    if (n_frames < 0 || (n_frames && (!d_syms || !d_ref_llr || !d_snr_lin))) return fail(DVBS2_EINVAL, "bad argument");
+    if (n_frames > h->dm->max_frames()) return fail(DVBS2_ESIZE, "n_frames exceeds max_frames");
+    if (h->dm->snr_device(d_syms, d_ref_llr, n_frames, d_snr_lin, (hipStream_t)stream)) return fail(DVBS2_EDEVICE, h->dm->error());
+    return DVBS2_OK;
+    API_CATCH
+}
+
+int dvbs2_demap_refine_snr(dvbs2_demap_t* h, const float* syms, const int8_t* ref_llr, int n_frames, float* snr_lin)
+{
+    API_TRY
+    if (!h) return fail(DVBS2_EINVAL, "null handle");
+    if (n_frames < 0 || (n_frames && (!syms || !ref_llr || !snr_lin))) return fail(DVBS2_EINVAL, "bad argument");
+    if (n_frames > h->dm->max_frames()) return fail(DVBS2_ESIZE, "n_frames exceeds max_frames");
+    if (n_frames == 0) return DVBS2_OK;
+    if (int rc = demap_stage(h, syms, n_frames)) return rc;
+    HCHK(hipMemcpyAsync(h->d_llr, ref_llr, (size_t)n_frames * h->dm->n_llr(), hipMemcpyHostToDevice, h->stream));
+    if (h->dm->snr_device(h->d_syms, h->d_llr, n_frames, h->d_snr, h->stream)) return fail(DVBS2_EDEVICE, h->dm->error());
     HCHK(hipMemcpyAsync(snr_lin, h->d_snr, (size_t)n_frames * 4, hipMemcpyDeviceToHost, h->stream));
     HCHK(hipStreamSynchronize(h->stream));
     return DVBS2_OK;

@@ -24,7 +24,8 @@ public:
     int soft_device(const float* d_syms, int n_frames, const float* d_n0, int n0_count, int8_t* d_llr, hipStream_t stream);
     // pre-decoder linear SNR per frame (lib/xfecframe_demapper_cb_impl.cc:128-149): float reduction,
     // order differs from the reference's sequential / VOLK accumulation -> tolerance only.
-    int snr_device(const float* d_syms, int n_frames, float* d_snr, hipStream_t stream);
+    // d_ref_llr != nullptr: post-decoder refinement against the decoded LLRs (:246-317)
+    int snr_device(const float* d_syms, const int8_t* d_ref_llr, int n_frames, float* d_snr, hipStream_t stream);
 
 private:
     int n_llr_ = 0, n_mod_ = 0, order_ = 0, constellation_ = 0, max_frames_ = 0, device_ = 0;

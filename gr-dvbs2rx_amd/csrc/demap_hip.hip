@@ -62,8 +62,12 @@ __global__ void demap_8psk_kernel(const float2* __restrict__ syms, const float* 
     }
 }
 
-__global__ void demap_snr_kernel(const float2* __restrict__ syms, float* __restrict__ snr, int n_syms, int constellation,
-                                 float rr, float ri)
+// One workgroup per frame. llr == nullptr: reference point = hard slice of the symbol (pre-decoder estimate);
+// otherwise the reference point is re-mapped from the signs of the decoded LLRs (post-decoder refinement,
+// lib/xfecframe_demapper_cb_impl.cc:268-307, lib/qpsk.h:266-281): LLR < 0 -> -1, else +1; 8PSK bits are picked
+// through the column interleaver (ra0..2 = d_rowaddr0..2).
+__global__ void demap_snr_kernel(const float2* __restrict__ syms, const int8_t* __restrict__ llr, float* __restrict__ snr,
+                                 int n_syms, int constellation, int ra0, int ra1, int ra2, float rr, float ri)
 {
     __shared__ float ssp[256], snp[256];
     const int f = blockIdx.x, tid = threadIdx.x;
@@ -72,10 +76,20 @@ __global__ void demap_snr_kernel(const float2* __restrict__ syms, float* __restr
     for (int j = tid; j < n_syms; j += blockDim.x) {
         const float2 c = syms[(size_t)f * n_syms + j];
         float sr, si;
-        if (constellation == DVBS2_MOD_QPSK) { sr = c.x >= 0 ? rs2 : -rs2; si = c.y >= 0 ? rs2 : -rs2; }
-        else {
-            const float cr = c.x * rr - c.y * ri, ci = c.x * ri + c.y * rr;
-            const int b1 = cr < 0 ? -1 : 1, b2 = ci < 0 ? -1 : 1, b0 = fabsf(cr) < fabsf(ci) ? -1 : 1;
+        if (constellation == DVBS2_MOD_QPSK) {
+            if (llr) {
+                const int8_t* l = llr + (size_t)f * 2 * n_syms + 2 * j;
+                sr = l[0] >= 0 ? rs2 : -rs2; si = l[1] >= 0 ? rs2 : -rs2;
+            } else { sr = c.x >= 0 ? rs2 : -rs2; si = c.y >= 0 ? rs2 : -rs2; }
+        } else {
+            int b0, b1, b2;
+            if (llr) {
+                const int8_t* l = llr + (size_t)f * 3 * n_syms;
+                b0 = l[ra0 + j] < 0 ? -1 : 1; b1 = l[ra1 + j] < 0 ? -1 : 1; b2 = l[ra2 + j] < 0 ? -1 : 1;
+            } else {
+                const float cr = c.x * rr - c.y * ri, ci = c.x * ri + c.y * rr;
+                b1 = cr < 0 ? -1 : 1; b2 = ci < 0 ? -1 : 1; b0 = fabsf(cr) < fabsf(ci) ? -1 : 1;
+            }
             const int idx = (((b0 + 1) << 1) ^ 0x4) | ((b1 + 1) ^ 0x2) | (((b2 + 1) >> 1) ^ 0x1);
             const float m8r[8] = { rs2, 1, -1, -rs2, 0, rs2, -rs2, 0 }, m8i[8] = { rs2, 0, 0, -rs2, 1, -rs2, rs2, -1 };
             sr = m8r[idx]; si = m8i[idx];
@@ -128,15 +142,19 @@ int DemapperHip::soft_device(const float* d_syms, int n_frames, const float* d_n
     return 0;
 }
 
-int DemapperHip::snr_device(const float* d_syms, int n_frames, float* d_snr, hipStream_t stream)
+int DemapperHip::snr_device(const float* d_syms, const int8_t* d_ref_llr, int n_frames, float* d_snr, hipStream_t stream)
 {
     if (!ok()) return -1;
     if (n_frames < 0 || n_frames > max_frames_) { err_ = "n_frames exceeds max_frames"; return -1; }
     if (n_frames == 0) return 0;
     if (hipSetDevice(device_) != hipSuccess) { err_ = "hipSetDevice failed"; return -1; }
     const float rr = (float)std::cos(-M_PI / 8), ri = (float)std::sin(-M_PI / 8);
+    const int rows = n_syms();
+    int ra0 = 0, ra1 = rows, ra2 = 2 * rows;
+    if (order_ == 1) { ra0 = 2 * rows; ra1 = rows; ra2 = 0; }
+    else if (order_ == 2) { ra0 = rows; ra1 = 0; ra2 = 2 * rows; }
     hipLaunchKernelGGL(demap_snr_kernel, dim3(n_frames), dim3(256), 0, stream,
-                       reinterpret_cast<const float2*>(d_syms), d_snr, n_syms(), constellation_, rr, ri);
+                       reinterpret_cast<const float2*>(d_syms), d_ref_llr, d_snr, rows, constellation_, ra0, ra1, ra2, rr, ri);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { err_ = std::string("snr kernel launch: ") + hipGetErrorString(e); return -1; }
     return 0;

@@ -16,6 +16,7 @@
 #include <cmath>
 #include <cstring>
 #include <functional>
+#include <limits>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -200,6 +201,11 @@ public:
                 const float n0 = 1.0f / d_snr_lin;
                 check(dvbs2_demap_soft(d_h, p, nf, &n0, 1, out + (size_t)done * d_fecframe_len));
             }
+            for (int i = 0; i < nf; i++) { // keep the XFECFRAMEs for the post-decoder refinement (:115-123)
+                d_saved[d_pool_idx] = d_frame_cnt + i;
+                std::memcpy(&d_pool[d_pool_idx * (size_t)d_xfecframe_len * 2], p + (size_t)i * d_xfecframe_len * 2, (size_t)d_xfecframe_len * 8);
+                d_pool_idx = (d_pool_idx + 1) % d_saved.size();
+            }
             done += nf; d_frame_cnt += nf;
         }
         *consumed = n_frames * d_xfecframe_len;
@@ -208,6 +214,33 @@ public:
     float get_snr() const { return 10.0f * std::log10(d_snr_lin); } // lib/xfecframe_demapper_cb_impl.h:74
     // refined (post-decoder) linear SNR, the result of the reference's handle_llr_pdu() (:188-318)
     void set_snr_lin(float snr_lin) { d_snr_lin = snr_lin; d_waiting_first_llr = false; }
+    // The llr_pdu message handler (lib/xfecframe_demapper_cb_impl.cc:188-318): frames starting_frame_cnt ..
+    // +simd_size-1 are looked up in the pool of saved XFECFRAMEs, the per-frame refined estimates (computed on the
+    // GPU in one call) are averaged and become the N0 of the frames demapped from now on. Returns the number of
+    // frames that were found (the reference logs and skips the others, :260-266); a malformed PDU is dropped.
+    int handle_llr_pdu(uint64_t starting_frame_cnt, int simd_size, const int8_t* llr, size_t n_llr)
+    {
+        if (n_llr == 0 || simd_size <= 0 || n_llr != (size_t)simd_size * d_fecframe_len) return 0; // :235-239
+        std::vector<float> syms; std::vector<int8_t> ref;
+        int found = 0;
+        for (int i = 0; i < simd_size; i++) {
+            size_t idx = d_saved.size();
+            for (size_t k = 0; k < d_saved.size(); k++) if (d_saved[k] == starting_frame_cnt + i) { idx = k; break; }
+            if (idx == d_saved.size()) continue;
+            syms.insert(syms.end(), &d_pool[idx * (size_t)d_xfecframe_len * 2], &d_pool[(idx + 1) * (size_t)d_xfecframe_len * 2]);
+            ref.insert(ref.end(), llr + (size_t)i * d_fecframe_len, llr + (size_t)(i + 1) * d_fecframe_len);
+            found++;
+        }
+        float accum = 0;
+        std::vector<float> snr(d_batch);
+        for (int done = 0; done < found; done += d_batch) {
+            const int nf = std::min(found - done, d_batch);
+            check(dvbs2_demap_refine_snr(d_h, &syms[(size_t)done * d_xfecframe_len * 2], &ref[(size_t)done * d_fecframe_len], nf, snr.data()));
+            for (int i = 0; i < nf; i++) accum += snr[i];
+        }
+        if (found > 0) { d_snr_lin = accum / found; d_waiting_first_llr = false; } // :309-317
+        return found;
+    }
 
 private:
     xfecframe_demapper_cb(dvb_framesize_t framesize, dvb_code_rate_t rate, dvb_constellation_t constellation, int batch_frames, int device) : d_batch(batch_frames)
@@ -215,6 +248,8 @@ private:
         check(dvbs2_demap_create(&d_h, framesize, rate, constellation, batch_frames, device)); // throws "Unsupported constellation"
         int order;
         check(dvbs2_demap_params(d_h, &d_xfecframe_len, &d_fecframe_len, &d_n_mod, &order));
+        d_saved.assign(std::max(64, 2 * batch_frames), std::numeric_limits<uint64_t>::max()); // XFECFRAME_POOL_SIZE, .h:28-32
+        d_pool.resize(d_saved.size() * (size_t)d_xfecframe_len * 2);
     }
     dvbs2_demap_t* d_h = nullptr;
     int d_xfecframe_len = 0, d_fecframe_len = 0, d_n_mod = 0, d_batch;
@@ -222,6 +257,9 @@ private:
     float d_snr_lin = 1.0f;
     uint64_t d_frame_cnt = 0;
     std::vector<float> d_n0;
+    std::vector<uint64_t> d_saved; // frame number held by each pool slot
+    std::vector<float> d_pool;     // saved XFECFRAMEs, interleaved (re, im)
+    size_t d_pool_idx = 0;
 };
 
 } // namespace dvbs2rx_hip

@@ -208,6 +208,16 @@ class Demapper:
         check(lib.dvbs2_demap_estimate_snr(self._h, syms.ctypes.data, nf, snr.ctypes.data))
         return snr
 
+    def refine_snr(self, syms, ref_llr):
+        """Post-decoder linear SNR per frame from the decoded LLRs (handle_llr_pdu, reference :268-307)."""
+        syms = np.ascontiguousarray(syms, dtype=np.complex64)
+        ref_llr = np.ascontiguousarray(ref_llr, dtype=np.int8)
+        nf = syms.shape[0]
+        assert ref_llr.shape == (nf, self.n_llr)
+        snr = np.empty(nf, np.float32)
+        check(lib.dvbs2_demap_refine_snr(self._h, syms.ctypes.data, ref_llr.ctypes.data, nf, snr.ctypes.data))
+        return snr
+
     def work_device(self, d_syms, n_frames, d_n0, n0_count, d_llr, stream=0):
         check(lib.dvbs2_demap_soft_device(self._h, d_syms, n_frames, d_n0, n0_count, d_llr, stream or None))
 

@@ -148,6 +148,16 @@ int dvbs2_demap_soft_device(dvbs2_demap_t* h, const float* d_syms, int n_frames,
 int dvbs2_demap_estimate_snr(dvbs2_demap_t* h, const float* syms, int n_frames, float* snr_lin);
 int dvbs2_demap_estimate_snr_device(dvbs2_demap_t* h, const float* d_syms, int n_frames, float* d_snr_lin,
                                     void* stream);
+/* post-decoder refinement, the per-frame body of handle_llr_pdu() (lib/xfecframe_demapper_cb_impl.cc:268-307;
+ * QPSK: QpskConstellation::estimate_snr(in, ref_llrs, n) lib/qpsk.h:266-281): the reference constellation point of
+ * every symbol is re-mapped from the signs of the decoded LLRs (ref_llr: n_frames * n_llr int8 in the decoder's
+ * natural bit order, LLR < 0 => bit 1; 8PSK bits are taken through the column interleaver), then
+ * snr = sum|ref|^2 / sum|x - ref|^2 per frame. The block averages the per-frame values of one llr_pdu and sets
+ * N0 = 1 / mean (:309-315). Same tolerance note as above. */
+int dvbs2_demap_refine_snr(dvbs2_demap_t* h, const float* syms, const int8_t* ref_llr, int n_frames,
+                           float* snr_lin);
+int dvbs2_demap_refine_snr_device(dvbs2_demap_t* h, const float* d_syms, const int8_t* d_ref_llr, int n_frames,
+                                  float* d_snr_lin, void* stream);
 
 /* ---- whole chain on the device: xfecframe_demapper_cb -> ldpc_decoder_bb (OM_MESSAGE) -> bch_decoder_bb,
  * as wired in apps/dvbs2-rx:853-863; intermediate LLRs and LDPC output stay in HBM ---- */

@@ -103,3 +103,35 @@ float oracle_demap_snr(const float* syms, int n_syms, int constellation)
     if (!(np > 0)) np = 1e-12f;
     return sp / np;
 }
+
+/* post-decoder refinement for one frame: lib/xfecframe_demapper_cb_impl.cc:268-307 (8PSK: signs of the decoded
+ * LLRs re-interleaved :274-291, mapped :297-302) and lib/qpsk.h:266-281 (QPSK: int8 -> float -> slice (>= 0 is
+ * the positive point, :171-181) -> _estimate_snr :41-65). order = 8PSK column order as in oracle_demap_8psk. */
+float oracle_demap_snr_refined(const float* syms, const int8_t* llr, int n_syms, int constellation, int order)
+{
+    const float rcp_sqrt_2 = 0.70710678118654752440f;
+    float sp = 0, np = 0;
+    if (constellation == 4) {
+        for (int j = 0; j < n_syms; j++) {
+            float sr = llr[2 * j] >= 0 ? rcp_sqrt_2 : -rcp_sqrt_2;
+            float si = llr[2 * j + 1] >= 0 ? rcp_sqrt_2 : -rcp_sqrt_2;
+            float er = syms[2 * j] - sr, ei = syms[2 * j + 1] - si;
+            sp += sr * sr + si * si; np += er * er + ei * ei;
+        }
+    } else {
+        static const float m8[8][2] = { { 0.70710678118654752440f, 0.70710678118654752440f }, { 1, 0 }, { -1, 0 },
+            { -0.70710678118654752440f, -0.70710678118654752440f }, { 0, 1 },
+            { 0.70710678118654752440f, -0.70710678118654752440f }, { -0.70710678118654752440f, 0.70710678118654752440f }, { 0, -1 } };
+        int rows = n_syms, ra0 = 0, ra1 = rows, ra2 = 2 * rows;
+        if (order == 1) { ra0 = 2 * rows; ra1 = rows; ra2 = 0; }
+        else if (order == 2) { ra0 = rows; ra1 = 0; ra2 = 2 * rows; }
+        for (int j = 0; j < n_syms; j++) {
+            int b0 = llr[ra0 + j] < 0 ? -1 : 1, b1 = llr[ra1 + j] < 0 ? -1 : 1, b2 = llr[ra2 + j] < 0 ? -1 : 1;
+            int idx = (((b0 + 1) << 1) ^ 0x4) | ((b1 + 1) ^ 0x2) | (((b2 + 1) >> 1) ^ 0x1);
+            float er = syms[2 * j] - m8[idx][0], ei = syms[2 * j + 1] - m8[idx][1];
+            sp += m8[idx][0] * m8[idx][0] + m8[idx][1] * m8[idx][1]; np += er * er + ei * ei;
+        }
+    }
+    if (!(np > 0)) np = 1e-12f;
+    return sp / np;
+}

@@ -55,6 +55,8 @@ def oracle():
         o.oracle_demap_8psk.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_void_p]
         o.oracle_demap_snr.argtypes = [C.c_void_p, C.c_int, C.c_int]
         o.oracle_demap_snr.restype = C.c_float
+        o.oracle_demap_snr_refined.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
+        o.oracle_demap_snr_refined.restype = C.c_float
         _oracle = o
     return _oracle
 

@@ -1,7 +1,7 @@
 // tests/host_blocks_main.cpp -- drives the C++ host mirror (gr-dvbs2rx_amd/host/dvbs2rx_hip_blocks.h) the way a
 // GNU Radio scheduler thread would: forecast() + general_work() on byte streams read from files written by
 // tests/test_host_blocks.py, which then compares the output streams with the CPU oracle.
-//   usage: host_blocks_main <ldpc|bch|demap> <in file> <out file> <framesize> <rate name> <arg>
+//   usage: host_blocks_main <ldpc|bch|demap|loop> <in file> <out file> <framesize> <rate name> <arg>
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
@@ -43,6 +43,31 @@ int main(int argc, char** argv)
             out.resize(nout); oo[0] = out.data();
             produced = b->general_work(nout, ninput, ii, oo, &consumed);
             std::printf("frames %llu errors %llu\n", (unsigned long long)b->get_frame_count(), (unsigned long long)b->get_error_count());
+        } else if (kind == "loop") {
+            // demapper -> LDPC with the llr_pdu port wired back into the demapper (apps/dvbs2-rx:853-863, 873):
+            // 32 frames demapped with the pre-decoder estimate, decoded, refined; then 32 more with the refined N0.
+            auto dm = xfecframe_demapper_cb::make(fs, rate, (dvb_constellation_t)arg, 64);
+            auto ld = ldpc_decoder_bb::make(STANDARD_DVBS2, fs, rate, (dvb_constellation_t)arg, OM_CODEWORD, INFO_OFF, 25, 0, 32, 64);
+            int found = 0;
+            ld->set_llr_pdu_handler([&](uint64_t fc, int simd, const int8_t* llr, size_t n) { found += dm->handle_llr_pdu(fc, simd, llr, n); });
+            const int nllr = dm->output_multiple() * 32;
+            std::vector<char> llr(nllr);
+            std::vector<char> bits(ld->output_multiple());
+            out.resize(2 * nllr);
+            for (int round = 0; round < 2; round++) {
+                dm->forecast(nllr, req);
+                gr_vector_const_void_star di(1, in.data() + (size_t)round * req[0] * 8);
+                gr_vector_void_star dout(1, out.data() + (size_t)round * nllr);
+                int c1 = 0, c2 = 0;
+                produced += dm->general_work(nllr, ninput, di, dout, &c1);
+                consumed += c1;
+                if (round == 0) {
+                    gr_vector_const_void_star li(1, dout[0]);
+                    gr_vector_void_star lo(1, bits.data());
+                    ld->general_work((int)bits.size(), ninput, li, lo, &c2);
+                    std::printf("found %d snr_lin %.6f\n", found, std::pow(10.0, dm->get_snr() / 10.0));
+                }
+            }
         } else {
             auto b = xfecframe_demapper_cb::make(fs, rate, (dvb_constellation_t)arg);
             int nout = b->output_multiple() * 2;

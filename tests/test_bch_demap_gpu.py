@@ -130,6 +130,32 @@ def test_8psk_demap_bit_exact(rate, order):
     dm.close()
 
 
+@pytest.mark.parametrize("constellation,rate,order", [(capi.MOD_QPSK, "C1_2", 0), (capi.MOD_8PSK, "C3_4", 0),
+                                                      (capi.MOD_8PSK, "C3_5", 1), (capi.MOD_8PSK, "C25_36", 2)])
+def test_snr_refinement_from_decoded_llrs(constellation, rate, order):
+    """handle_llr_pdu's per-frame estimate (reference :268-307): reference points from the signs of decoded LLRs."""
+    dm = Demapper(framesize=capi.FECFRAME_NORMAL, rate=rate, constellation=constellation, max_frames=4)
+    rng = np.random.default_rng(11)
+    llr = rng.integers(-128, 128, (4, dm.n_llr)).astype(np.int8)
+    llr[0, :64] = 0  # zero LLR counts as positive
+    # symbols = points re-mapped from those LLRs + noise of known power => snr ~ 1 / (2 sigma^2)
+    bits = (llr < 0).astype(np.uint8)
+    if constellation == capi.MOD_QPSK:
+        pts = ((1 - 2.0 * bits[:, 0::2]) + 1j * (1 - 2.0 * bits[:, 1::2])) * np.sqrt(0.5)
+    else:
+        rows = dm.n_syms
+        ra = {0: (0, rows, 2 * rows), 1: (2 * rows, rows, 0), 2: (rows, 0, 2 * rows)}[order]
+        pts = T.map_8psk(np.stack([bits[:, ra[c]:ra[c] + rows] for c in range(3)], axis=-1))
+    sigma = np.array([0.05, 0.2, 0.4, 0.7])[:, None]
+    syms = (pts + sigma * (rng.normal(size=pts.shape) + 1j * rng.normal(size=pts.shape))).astype(np.complex64)
+    snr = dm.refine_snr(syms, llr)
+    want = [T.oracle().oracle_demap_snr_refined(T.ptr(np.ascontiguousarray(syms[f])), T.ptr(llr[f]), dm.n_syms,
+                                               4 if constellation == capi.MOD_QPSK else 8, order) for f in range(4)]
+    assert np.allclose(snr, want, rtol=2e-4)  # float reduction order differs from the sequential restatement
+    assert np.allclose(snr, 1 / (2 * sigma[:, 0] ** 2), rtol=0.05)
+    dm.close()
+
+
 def test_unsupported_constellation_rejected():
     import ctypes as C
     h = C.c_void_p()

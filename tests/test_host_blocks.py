@@ -63,3 +63,29 @@ def test_demapper_block_stream(exe, tmp_path):
     want = T.oracle_demap(syms, np.float32(1.0) / np.float32(10.0), 4)
     assert np.array_equal(out.view(np.int8).reshape(2, -1), want)
     assert "snr_db 10.000" in log
+
+
+def test_demapper_llr_pdu_feedback_loop(exe, tmp_path):
+    """demapper -> LDPC -> llr_pdu -> demapper.handle_llr_pdu (reference :188-318): the first 32 frames use the
+    per-frame pre-decoder N0, the refinement averages the per-frame post-decoder estimates, frames 32..63 use it."""
+    table = "S2_TABLE_C1"
+    N, K, _, _ = T.ldpc_info(table)
+    rng = np.random.default_rng(17)
+    cw = T.ldpc_encode(table, rng.integers(0, 2, (64, K), dtype=np.uint8))
+    pts = ((1 - 2.0 * cw[:, 0::2]) + 1j * (1 - 2.0 * cw[:, 1::2])) * np.sqrt(0.5)
+    syms = (pts + 0.55 * (rng.normal(size=pts.shape) + 1j * rng.normal(size=pts.shape))).astype(np.complex64)
+    out, log = run(exe, tmp_path, "loop", syms, capi.FECFRAME_SHORT, "C1_4", capi.MOD_QPSK)
+    out = out.view(np.int8).reshape(64, N)
+    o = T.oracle()
+    pre = np.array([o.oracle_demap_snr(T.ptr(np.ascontiguousarray(syms[f])), N // 2, 4) for f in range(32)], np.float32)
+    llr0 = T.oracle_demap(syms[:32], np.float32(1.0) / pre, 4)
+    # N0 is a float reduction (tolerance 2e-4): allow the rare LLR that sits on a rounding boundary
+    assert np.mean(out[:32] != llr0) < 1e-3 and np.abs(out[:32].astype(int) - llr0).max() <= 1
+    dec, _ = T.oracle_ldpc_decode(table, out[:32], 32, 25)
+    ref = np.float32(np.mean([o.oracle_demap_snr_refined(T.ptr(np.ascontiguousarray(syms[f])), T.ptr(np.ascontiguousarray(dec[f])),
+                                                         N // 2, 4, 0) for f in range(32)]))
+    got = float(log.split("snr_lin")[1].split()[0])
+    assert "found 32" in log and abs(got - ref) / ref < 5e-4
+    assert abs(ref - 1 / (2 * 0.55 ** 2)) / ref < 0.05  # decoded frames => the true SNR
+    llr1 = T.oracle_demap(syms[32:], np.float32(1.0) / np.float32(got), 4)
+    assert np.mean(out[32:] != llr1) < 1e-3 and np.abs(out[32:].astype(int) - llr1).max() <= 1
