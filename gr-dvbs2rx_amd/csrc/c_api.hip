@@ -58,6 +58,12 @@ int dvbs2_rate_from_name(const char* name)
     return -1;
 }
 
+const char* dvbs2_ldpc_table_name(int index)
+{
+    const LdpcTableDesc* t = ldpc_table_at(index);
+    return t ? t->name : nullptr;
+}
+
 int dvbs2_ldpc_table_info(const char* table, int* n, int* k, int* q, int* links_total, int* conflict_layers)
 {
     API_TRY

@@ -13,7 +13,8 @@ import numpy as np
 from . import capi
 from .capi import lib, check
 
-__all__ = ["get_fec_info", "rate_id", "LdpcDecoder", "BchDecoder", "Demapper", "FecChain", "ldpc_table_info", "ldpc_layer_info"]
+__all__ = ["get_fec_info", "rate_id", "LdpcDecoder", "BchDecoder", "Demapper", "FecChain", "ldpc_table_info", "ldpc_layer_info",
+           "ldpc_table_names"]
 
 DEFAULT_TRIALS = 25  # reference lib/ldpc_decoder_bb_impl.cc:391
 
@@ -38,6 +39,17 @@ def ldpc_table_info(table):
     v = [C.c_int() for _ in range(5)]
     check(lib.dvbs2_ldpc_table_info(table.encode(), *v))
     return dict(zip(("N", "K", "q", "links_total", "conflict_layers"), (x.value for x in v)))
+
+
+def ldpc_table_names():
+    """Names of all built-in LDPC tables (the reference's DVB_*_TABLE_* structs)."""
+    out, i = [], 0
+    while True:
+        n = lib.dvbs2_ldpc_table_name(i)
+        if n is None:
+            return out
+        out.append(n.decode())
+        i += 1
 
 
 def ldpc_layer_info(table, layer):

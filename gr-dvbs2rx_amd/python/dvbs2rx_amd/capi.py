@@ -41,6 +41,7 @@ SYMBOLS = {
     "dvbs2_rate_name": (C.c_char_p, [_i]),
     "dvbs2_rate_from_name": (_i, [C.c_char_p]),
     "dvbs2_ldpc_table_info": (_i, [C.c_char_p, _ip, _ip, _ip, _ip, _ip]),
+    "dvbs2_ldpc_table_name": (C.c_char_p, [_i]),
     "dvbs2_ldpc_layer_info": (_i, [C.c_char_p, _i, _ip, _vp, _vp, _i]),
     "dvbs2_ldpc_create": (_i, [C.POINTER(_vp), _i, _i, _i, _i, _i, _i]),
     "dvbs2_ldpc_create_table": (_i, [C.POINTER(_vp), C.c_char_p, _i, _i, _i, _i]),

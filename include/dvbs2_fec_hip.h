@@ -64,6 +64,9 @@ int dvbs2_rate_from_name(const char* name);
  * layer as derived from the accumulator-address table; used by the tests of the schedule compiler.
  * Returns the number of data entries of the layer (<0 on error). groups/shifts may be NULL. ---- */
 int dvbs2_ldpc_table_info(const char* table, int* n, int* k, int* q, int* links_total, int* conflict_layers);
+/* names of the built-in tables ("S2_TABLE_B4", "S2X_TABLE_C8", "T2_TABLE_A3", ...: the reference's DVB_*_TABLE_*
+ * structs, lib/dvb_s2_tables.hh, dvb_s2x_tables.hh, dvb_t2_tables.hh) for index 0, 1, ...; NULL past the end */
+const char* dvbs2_ldpc_table_name(int index);
 int dvbs2_ldpc_layer_info(const char* table, int layer, int* block, int* groups, int* shifts, int max_entries);
 
 /* ---- LDPC: replaces ldpc_*::ldpc_dec_init + ldpc_*::ldpc_dec_decode as called by

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 import fec_testlib as T
-from dvbs2rx_amd import LdpcDecoder, capi
+from dvbs2rx_amd import ldpc_table_names, LdpcDecoder, capi
 
 pytestmark = pytest.mark.gpu
 
@@ -57,6 +57,18 @@ def test_near_threshold_groups(table, amp, sigma, G):
     llr, _ = T.llr_codeword_awgn(table, 64, 99, amp=amp, sigma=sigma)
     ret = compare(table, llr, G, 50)
     assert len(ret) == 64 // G
+
+
+@pytest.mark.parametrize("table", ldpc_table_names())
+def test_every_table_bit_exact(table):
+    """All 57 DVB-S2 / S2X / T2 tables of the reference: never-converging input (fixed trip count)
+    and noisy codewords (groups converge at different counts), bit-exact LLRs, bits and return values."""
+    N = T.ldpc_info(table)[0]
+    assert compare(table, T.llr_noise(32, N, 777), 32, 3).tolist() == [-1]
+    llr, _ = T.llr_codeword_awgn(table, 32, 4242, amp=12, sigma=3.0)
+    llr[5] = T.llr_noise(1, N, 778)[0]  # one hopeless frame keeps its group of 16 running to the cap
+    ret = compare(table, llr, 16, 12)
+    assert ret[0] == -1
 
 
 def test_group_of_one_and_tail():
