@@ -33,6 +33,8 @@ public:
     // d_msg: n_frames * k/8 bytes; d_corr: per frame  >= 0 corrected bits, -1 failure, -2 the reference would
     // have thrown (lib/gf.h:110 via lib/bch.cc:359-367, or lib/bch.cc:443-444).
     int decode_device(const uint8_t* d_cw, int n_frames, uint8_t* d_msg, int32_t* d_corr, hipStream_t stream);
+    // fuse bbdescrambler_bb (lib/bbdescrambler_bb_impl.cc:67-82) into the output stage: msg ^= PRBS
+    int set_descramble(bool enable);
 
 private:
     BchCode code_;
@@ -40,9 +42,14 @@ private:
     uint16_t* d_antilog_ = nullptr;
     uint16_t* d_log_ = nullptr;
     uint16_t* d_quad_ = nullptr;
+    uint8_t* d_scramble_ = nullptr;
+    bool descramble_ = false;
     int n_cus_ = 0;
     size_t lds_bytes_ = 0;
     std::string err_;
 };
+
+// the BBFRAME energy-dispersal sequence as packed bytes (host), lib/bbdescrambler_bb_impl.cc:51-65
+void bb_derandomise_sequence(uint8_t* seq, int n_bytes);
 
 } // namespace dvbs2

@@ -76,6 +76,7 @@ constexpr int kMaxT = 12;
 struct BchArgs {
     const uint16_t* antilog; const uint16_t* log; const uint16_t* quad;
     const uint8_t* cw; uint8_t* msg; int32_t* corr;
+    const uint8_t* descramble; // k/8 bytes of the BB PRBS or nullptr (fused bbdescrambler_bb)
     int n_frames, m, P, t, n, k, s;
 };
 
@@ -111,7 +112,10 @@ __global__ __launch_bounds__(kBchThreads) void bch_decode_kernel(BchArgs a)
         __syncthreads();
         const uint8_t* cw = a.cw + (size_t)f * nb;
         uint8_t* out = a.msg + (size_t)f * kb;
-        for (int b = tid; b < nb; b += kBchThreads) { const uint8_t v = cw[b]; cwl[b] = v; if (b < kb) out[b] = v; } // lib/bch.cc:471
+        for (int b = tid; b < nb; b += kBchThreads) { // lib/bch.cc:471 (+ lib/bbdescrambler_bb_impl.cc:74-78 when fused)
+            const uint8_t v = cw[b]; cwl[b] = v;
+            if (b < kb) out[b] = a.descramble ? (uint8_t)(v ^ a.descramble[b]) : v;
+        }
         if (tid < 2 * kMaxT) S[tid] = 0;
         if (tid == 0) { ctl[0] = 0; ctl[1] = 0; ctl[2] = 0; ctl[3] = 0; }
         __syncthreads();
@@ -272,9 +276,39 @@ BchDecoderHip::BchDecoderHip(int m, uint32_t prim_poly, int t, int n, int max_fr
 #undef HIP_OK
 }
 
+// lib/bbdescrambler_bb_impl.cc:51-65: PRBS 1 + x^14 + x^15, register loaded with 100101010000000, MSB-first bytes.
+void bb_derandomise_sequence(uint8_t* seq, int n_bytes)
+{
+    uint32_t reg = 0x4A80;
+    for (int i = 0; i < n_bytes; i++) {
+        uint8_t v = 0;
+        for (int bit = 7; bit >= 0; bit--) {
+            const uint32_t fb = (reg ^ (reg >> 1)) & 1u;
+            v |= (uint8_t)(fb << bit);
+            reg = (reg >> 1) | (fb << 14);
+        }
+        seq[i] = v;
+    }
+}
+
+int BchDecoderHip::set_descramble(bool enable)
+{
+    if (!ok()) return -1;
+    if (hipSetDevice(device_) != hipSuccess) { err_ = "hipSetDevice failed"; return -1; }
+    if (enable && !d_scramble_) {
+        std::vector<uint8_t> seq(code_.k / 8);
+        bb_derandomise_sequence(seq.data(), (int)seq.size());
+        if (hipMalloc(&d_scramble_, seq.size()) != hipSuccess ||
+            hipMemcpy(d_scramble_, seq.data(), seq.size(), hipMemcpyHostToDevice) != hipSuccess) { err_ = "descramble sequence upload failed"; return -1; }
+    }
+    descramble_ = enable;
+    return 0;
+}
+
 BchDecoderHip::~BchDecoderHip()
 {
     (void)hipSetDevice(device_);
+    (void)hipFree(d_scramble_);
     (void)hipFree(d_antilog_); (void)hipFree(d_log_); (void)hipFree(d_quad_);
 }
 
@@ -286,6 +320,7 @@ int BchDecoderHip::decode_device(const uint8_t* d_cw, int n_frames, uint8_t* d_m
     if (hipSetDevice(device_) != hipSuccess) { err_ = "hipSetDevice failed"; return -1; }
     BchArgs a;
     a.antilog = d_antilog_; a.log = d_log_; a.quad = d_quad_; a.cw = d_cw; a.msg = d_msg; a.corr = d_corr;
+    a.descramble = descramble_ ? d_scramble_ : nullptr;
     a.n_frames = n_frames; a.m = code_.m; a.P = code_.P; a.t = code_.t; a.n = code_.n; a.k = code_.k; a.s = code_.s;
     const int grid = std::min(n_frames, std::max(1, n_cus_));
     hipLaunchKernelGGL(bch_decode_kernel, dim3(grid), dim3(kBchThreads), lds_bytes_, stream, a);

@@ -292,6 +292,22 @@ int dvbs2_bch_genpoly(const dvbs2_bch_t* h, uint8_t* gen, int max_coefs)
     return h->dec->code().gdeg;
 }
 
+int dvbs2_bch_set_descramble(dvbs2_bch_t* h, int enable)
+{
+    API_TRY
+    if (!h) return fail(DVBS2_EINVAL, "null handle");
+    if (h->dec->set_descramble(enable != 0)) return fail(DVBS2_EDEVICE, h->dec->error());
+    return DVBS2_OK;
+    API_CATCH
+}
+
+int dvbs2_bb_descramble_sequence(uint8_t* seq, int n_bytes)
+{
+    if (!seq || n_bytes < 0 || n_bytes > 64800 / 8) return fail(DVBS2_EINVAL, "bad argument");
+    bb_derandomise_sequence(seq, n_bytes);
+    return DVBS2_OK;
+}
+
 int dvbs2_bch_decode_device(dvbs2_bch_t* h, const uint8_t* d_cw, int n_frames, uint8_t* d_msg, int32_t* d_corr, void* stream)
 {
     API_TRY
@@ -474,6 +490,12 @@ struct dvbs2_chain {
 };
 
 extern "C" {
+
+int dvbs2_chain_set_descramble(dvbs2_chain_t* h, int enable)
+{
+    if (!h) return fail(DVBS2_EINVAL, "null handle");
+    return dvbs2_bch_set_descramble(h->bch, enable);
+}
 
 void dvbs2_chain_destroy(dvbs2_chain_t* h)
 {

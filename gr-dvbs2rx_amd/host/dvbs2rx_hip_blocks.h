@@ -128,6 +128,8 @@ public:
     {
         return sptr(new bch_decoder_bb(standard, framesize, rate, batch_frames, device));
     }
+    // also run the next block of the flowgraph, bbdescrambler_bb (lib/bbdescrambler_bb_impl.cc:67-82), in the same kernel
+    void set_descramble(bool enable) { check(dvbs2_bch_set_descramble(d_h, enable ? 1 : 0)); }
     ~bch_decoder_bb() { dvbs2_bch_destroy(d_h); }
     void forecast(int noutput_items, gr_vector_int& req) const { req[0] = (noutput_items / d_k_bytes) * d_n_bytes; } // :78-82
     int output_multiple() const { return d_k_bytes; }

@@ -14,7 +14,7 @@ from . import capi
 from .capi import lib, check
 
 __all__ = ["get_fec_info", "rate_id", "LdpcDecoder", "BchDecoder", "Demapper", "FecChain", "ldpc_table_info", "ldpc_layer_info",
-           "ldpc_table_names"]
+           "ldpc_table_names", "bb_descramble_sequence"]
 
 DEFAULT_TRIALS = 25  # reference lib/ldpc_decoder_bb_impl.cc:391
 
@@ -39,6 +39,13 @@ def ldpc_table_info(table):
     v = [C.c_int() for _ in range(5)]
     check(lib.dvbs2_ldpc_table_info(table.encode(), *v))
     return dict(zip(("N", "K", "q", "links_total", "conflict_layers"), (x.value for x in v)))
+
+
+def bb_descramble_sequence(n_bytes):
+    """The BBFRAME energy-dispersal PRBS as packed bytes (reference lib/bbdescrambler_bb_impl.cc:51-65)."""
+    seq = np.zeros(n_bytes, np.uint8)
+    check(lib.dvbs2_bb_descramble_sequence(seq.ctypes.data, n_bytes))
+    return seq
 
 
 def ldpc_table_names():
@@ -162,6 +169,10 @@ class BchDecoder:
         except Exception:
             pass
 
+    def set_descramble(self, enable=True):
+        """Fuse bbdescrambler_bb (reference lib/bbdescrambler_bb_impl.cc:67-82) into the output stage."""
+        check(lib.dvbs2_bch_set_descramble(self._h, int(bool(enable))))
+
     def genpoly(self):
         g = np.zeros(256, np.uint8)
         deg = check(lib.dvbs2_bch_genpoly(self._h, g.ctypes.data, 256))
@@ -258,6 +269,9 @@ class FecChain:
             self.close()
         except Exception:
             pass
+
+    def set_descramble(self, enable=True):
+        check(lib.dvbs2_chain_set_descramble(self._h, int(bool(enable))))
 
     def work_device(self, d_syms, n_frames, d_n0, n0_count, d_msg, d_ldpc_ret=0, d_bch_corr=0, stream=0):
         check(lib.dvbs2_chain_decode_device(self._h, d_syms, n_frames, d_n0, n0_count, self.max_trials, d_msg,

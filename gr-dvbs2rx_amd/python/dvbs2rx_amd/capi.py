@@ -56,6 +56,8 @@ SYMBOLS = {
     "dvbs2_bch_params": (_i, [_vp, _ip, _ip, _ip]),
     "dvbs2_bch_genpoly": (_i, [_vp, _vp, _i]),
     "dvbs2_bch_decode": (_i, [_vp, _vp, _i, _vp, _vp]),
+    "dvbs2_bch_set_descramble": (_i, [_vp, _i]),
+    "dvbs2_bb_descramble_sequence": (_i, [_vp, _i]),
     "dvbs2_bch_decode_device": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
     "dvbs2_demap_create": (_i, [C.POINTER(_vp), _i, _i, _i, _i, _i]),
     "dvbs2_demap_destroy": (None, [_vp]),
@@ -69,6 +71,7 @@ SYMBOLS = {
     "dvbs2_chain_create": (_i, [C.POINTER(_vp), _i, _i, _i, _i, _i, _i, _i]),
     "dvbs2_chain_destroy": (None, [_vp]),
     "dvbs2_chain_params": (_i, [_vp, _ip, _ip]),
+    "dvbs2_chain_set_descramble": (_i, [_vp, _i]),
     "dvbs2_chain_decode_device": (_i, [_vp, _vp, _i, _vp, _i, _i, _vp, _vp, _vp, _vp]),
 }
 

@@ -122,6 +122,12 @@ int dvbs2_bch_genpoly(const dvbs2_bch_t* h, uint8_t* gen, int max_coefs);
  *              lib/gf.h:110 via lib/bch.cc:359-367; or "Error location number out of range", lib/bch.cc:443-444)
  */
 int dvbs2_bch_decode(dvbs2_bch_t* h, const uint8_t* cw, int n_frames, uint8_t* msg, int32_t* corrections);
+/* Fuse the next block of the flowgraph, bbdescrambler_bb (reference lib/bbdescrambler_bb_impl.cc:67-82,
+ * apps/dvbs2-rx:863-864), into the decoder's output stage: msg[j] ^= PRBS[j], j < k/8, per frame. Off by default. */
+int dvbs2_bch_set_descramble(dvbs2_bch_t* h, int enable);
+/* the BBFRAME energy-dispersal sequence itself (1 + x^14 + x^15, register 100101010000000, packed MSB first;
+ * reference init_bb_derandomiser(), lib/bbdescrambler_bb_impl.cc:51-65), host only; n_bytes <= 8100 */
+int dvbs2_bb_descramble_sequence(uint8_t* seq, int n_bytes);
 int dvbs2_bch_decode_device(dvbs2_bch_t* h, const uint8_t* d_cw, int n_frames, uint8_t* d_msg,
                             int32_t* d_corrections, void* stream);
 
@@ -170,6 +176,8 @@ int dvbs2_chain_create(dvbs2_chain_t** h, int standard, int framesize, int rate,
 void dvbs2_chain_destroy(dvbs2_chain_t* h);
 /* bytes per frame out (bch k / 8), symbols per frame in */
 int dvbs2_chain_params(const dvbs2_chain_t* h, int* n_syms, int* msg_bytes);
+/* also apply bbdescrambler_bb in the BCH output stage (dvbs2_bch_set_descramble) */
+int dvbs2_chain_set_descramble(dvbs2_chain_t* h, int enable);
 /* d_msg: n_frames * bch_k/8; d_ldpc_ret (nullable): one per LDPC group; d_bch_corr (nullable -> internal): per frame */
 int dvbs2_chain_decode_device(dvbs2_chain_t* h, const float* d_syms, int n_frames, const float* d_n0, int n0_count,
                               int max_trials, uint8_t* d_msg, int32_t* d_ldpc_ret, int32_t* d_bch_corr, void* stream);

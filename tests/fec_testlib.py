@@ -16,7 +16,7 @@ ORACLE_DIR = os.path.join(ROOT, "oracle")
 
 def _build_oracle():
     so = os.path.join(ORACLE_DIR, "liboracle.so")
-    srcs = [os.path.join(ORACLE_DIR, f) for f in ("ldpc_oracle.c", "bch_oracle.c", "demap_oracle.c")]
+    srcs = [os.path.join(ORACLE_DIR, f) for f in ("ldpc_oracle.c", "bch_oracle.c", "demap_oracle.c", "bb_oracle.c")]
     if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["make", "-C", ORACLE_DIR, "liboracle.so"], stdout=subprocess.DEVNULL)
     return so
@@ -57,6 +57,8 @@ def oracle():
         o.oracle_demap_snr.restype = C.c_float
         o.oracle_demap_snr_refined.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
         o.oracle_demap_snr_refined.restype = C.c_float
+        o.oracle_bb_sequence.argtypes = [C.c_void_p, C.c_int]
+        o.oracle_bb_descramble.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
         _oracle = o
     return _oracle
 
@@ -257,3 +259,11 @@ def map_8psk(bits3):
     b = 1 - 2 * bits3.astype(np.int32)  # bit 0 -> +1, bit 1 -> -1 (positive LLR = bit 0)
     idx = (((b[..., 0] + 1) << 1) ^ 0x4) | ((b[..., 1] + 1) ^ 0x2) | (((b[..., 2] + 1) >> 1) ^ 0x1)
     return M8PSK[idx]
+
+
+def oracle_bb_descramble(msg):
+    """msg: (n_frames, kbch_bytes) uint8 -> descrambled copy (lib/bbdescrambler_bb_impl.cc:67-82)."""
+    msg = np.ascontiguousarray(msg, np.uint8)
+    out = np.empty_like(msg)
+    oracle().oracle_bb_descramble(ptr(msg), ptr(out), msg.shape[1], msg.shape[0])
+    return out

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 import fec_testlib as T
-from dvbs2rx_amd import BchDecoder, Demapper, FecChain, LdpcDecoder, capi, get_fec_info
+from dvbs2rx_amd import BchDecoder, Demapper, FecChain, LdpcDecoder, bb_descramble_sequence, capi, get_fec_info
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(T.ROOT, "tests", "golden")
@@ -48,6 +48,31 @@ def test_bch_error_patterns(framesize, rate):
     ok = [i for i, c in enumerate(counts) if c <= t]
     assert np.array_equal(out[ok], msg[ok]) and ret[ok].tolist() == [counts[i] for i in ok]
     assert dec.frame_error_cnt == int((wret == -1).sum())
+    dec.close()
+
+
+@pytest.mark.parametrize("framesize,rate", [(capi.FECFRAME_NORMAL, "C1_2"), (capi.FECFRAME_SHORT, "C1_4"),
+                                            (capi.FECFRAME_NORMAL, "C9_10")])
+def test_bch_fused_bb_descrambler(framesize, rate):
+    """bch_decoder_bb -> bbdescrambler_bb (reference lib/bbdescrambler_bb_impl.cc:67-82) in one kernel: corrected,
+    uncorrectable and clean frames; switching the fusion off restores the plain output."""
+    ob, fi = bch_pair(framesize, rate)
+    t, n, k = fi["bch_t"], fi["bch_n"], fi["bch_k"]
+    dec = BchDecoder(framesize=framesize, rate=rate, max_frames=6)
+    rng = np.random.default_rng(77)
+    msg = rng.integers(0, 256, (6, k // 8), dtype=np.uint8)
+    cw = ob.encode_bytes(msg)
+    rx = np.stack([T.flip_bits(cw[i], rng.choice(n, [0, 1, t, t + 3, 40, 2][i], replace=False)) for i in range(6)])
+    want, wret = ob.decode_bytes(rx)
+    plain, ret = dec.work(rx)
+    assert np.array_equal(plain, want) and ret.tolist() == wret.tolist()
+    dec.set_descramble(True)
+    got, ret = dec.work(rx)
+    assert ret.tolist() == wret.tolist()
+    assert np.array_equal(got, T.oracle_bb_descramble(want))
+    assert np.array_equal(got[0] ^ msg[0], bb_descramble_sequence(k // 8))
+    dec.set_descramble(False)
+    assert np.array_equal(dec.work(rx)[0], want)
     dec.close()
 
 
@@ -201,4 +226,11 @@ def test_chain_8psk_3_4_normal():
     assert d_corr.cpu().numpy().tolist() == want_corr.tolist()
     assert np.array_equal(d_msg.cpu().numpy(), want_msg)
     assert np.array_equal(want_msg[:nf - 1], msg[:nf - 1])  # the good frames decode to what was sent
+    # same batch with bbdescrambler_bb fused into the BCH output stage
+    chain.set_descramble(True)
+    chain.work_device(d_syms.data_ptr(), nf, d_n0.data_ptr(), 1, d_msg.data_ptr(), d_ret.data_ptr(), d_corr.data_ptr(),
+                      torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert d_corr.cpu().numpy().tolist() == want_corr.tolist()
+    assert np.array_equal(d_msg.cpu().numpy(), T.oracle_bb_descramble(want_msg))
     chain.close()

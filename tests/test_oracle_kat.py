@@ -138,6 +138,19 @@ def test_ldpc_oracle_vs_reference_live():
 
 
 # ------------------------------------------------------------------ product host logic (no device needed)
+def test_bb_descrambler_sequence_known_answer():
+    """DVB energy-dispersal PRBS (EN 302 307-1 clause 5.2.2 / EN 300 421 clause 4.4.1): published first bytes; the
+    product's host-side sequence equals the oracle's over a whole normal BBFRAME."""
+    from dvbs2rx_amd import bb_descramble_sequence
+    seq = np.zeros(8100, np.uint8)
+    T.oracle().oracle_bb_sequence(T.ptr(seq), 8100)
+    assert bytes(seq[:8]).hex() == "03f6083430b8a393"
+    assert np.array_equal(bb_descramble_sequence(8100), seq)
+    x = np.arange(2 * 4026, dtype=np.uint32).astype(np.uint8).reshape(2, 4026)
+    assert np.array_equal(T.oracle_bb_descramble(T.oracle_bb_descramble(x)), x)  # involution
+    assert np.array_equal(T.oracle_bb_descramble(x)[1], x[1] ^ seq[:4026])
+
+
 def test_fec_params_match_reference():
     """gr-dvbs2rx_amd's parameter map vs the reference's get_fec_info() + table switch (tests/golden/fec_params.json)."""
     g = json.load(open(os.path.join(GOLD, "fec_params.json")))
