@@ -46,6 +46,31 @@ __device__ __forceinline__ int mag_offset(int Lb, int mb)
     asm("v_med3_i32 %0, %1, 0, %2" : "=v"(r) : "v"(a), "s"(126));
     return r;
 }
+// R3: the two smallest of N magnitudes. The kernel is bound by the VALU pipe and min/max/med3 are half-rate
+// there, so the count matters: triples go through v_min3 + v_med3 (smallest and second smallest of three in two
+// instructions), two sorted pairs merge in three, a single value folds in with two -- 9 instructions for seven
+// values where the running (min0, min1) update needs 14.
+__device__ __forceinline__ int vmin3_i32(int a, int b, int c) { int r; asm("v_min3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ int vmed3_i32(int a, int b, int c) { int r; asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+template <int N>
+__device__ __forceinline__ void two_smallest(const int* v, int& m0, int& m1)
+{
+    static_assert(N >= 1, "empty set");
+    int k;
+    if constexpr (N == 1) { m0 = v[0]; m1 = 127; k = 1; }
+    else if constexpr (N == 2) { m0 = min(v[0], v[1]); m1 = max(v[0], v[1]); k = 2; }
+    else { m0 = vmin3_i32(v[0], v[1], v[2]); m1 = vmed3_i32(v[0], v[1], v[2]); k = 3; }
+#pragma unroll
+    for (; k + 3 <= N; k += 3) {
+        const int g0 = vmin3_i32(v[k], v[k + 1], v[k + 2]), g1 = vmed3_i32(v[k], v[k + 1], v[k + 2]);
+        const int t = max(m0, g0);
+        m0 = min(m0, g0);
+        m1 = vmin3_i32(t, m1, g1);
+    }
+#pragma unroll
+    for (; k < N; k++) { m1 = vmed3_i32(m0, m1, v[k]); m0 = min(m0, v[k]); }
+}
+
 // low bytes of four 32-bit values -> one dword (two v_perm_b32 + or)
 __device__ __forceinline__ uint32_t pack4_lo8(int a, int b, int c, int d)
 {
@@ -99,11 +124,9 @@ __device__ __forceinline__ void check_node(uint8_t* __restrict__ lds, const uint
         int mag = mag_offset(Lb[k], mb);
         if (LAYER0 && k == DEG - 1) { d = last_valid ? d : 0; mag = last_valid ? mag : 127; }
         inp[k] = d; mg[k] = mag;
-        // R3 two smallest magnitudes (new min1 = median(min0, min1, mag)); R4 xor of the sign bits
-        min1 = min(max(mag, min0), min1);
-        min0 = min(min0, mag);
-        signs ^= d;
+        signs ^= d; // R4 xor of the sign bits
     }
+    two_smallest<DEG>(mg, min0, min1); // R3
     const int s01 = min0 + min1;
     int msgc[4 * ((DEG + 3) / 4)];
 #pragma unroll
@@ -171,11 +194,10 @@ __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, con
                 int mag = mag_offset(Lb, mb);
                 if (LAYER0 && k == DEG - 1) { d = last_valid ? d : 0; mag = last_valid ? mag : 127; }
                 inp[k] = d; mg[k] = mag;
-                min1 = min(max(mag, min0), min1);
-                min0 = min(min0, mag);
                 signs ^= d;
             }
         }
+        two_smallest<DEG - NC>(mg + NC, min0, min1);
     }
 #pragma unroll
     for (int w = 0; w < (DEG + 3) / 4; w++) nm[w] = 0;

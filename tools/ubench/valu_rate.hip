@@ -80,6 +80,20 @@ DEF(mov_b32, "v_mov_b32 %0, %1")
 DEF(alignbit, "v_alignbit_b32 %0, %0, %1, %2")
 DEF(fma_mix, "v_fma_f32 %0, %0, %1, 1.0")
 DEF(subrev_f32_neg, "v_sub_f32 %0, -%0, %1")
+DEF(sub_i32_clamp, "v_sub_i32 %0, %0, %1 clamp")
+DEF(add_i32_clamp, "v_add_i32 %0, %0, %1 clamp")
+DEF(sub_u32_clamp, "v_sub_u32_e64 %0, %0, %1 clamp")
+DEF(add_u32_e64, "v_add_u32_e64 %0, %0, %1")
+DEF(lshl_sdwa, "v_lshlrev_b32_sdwa %0, %1, %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1")
+DEF(med3_u32, "v_med3_u32 %0, %0, %1, %2")
+DEF(max3_u32, "v_max3_u32 %0, %0, %1, %2")
+DEF(add_i16_clamp, "v_add_i16 %0, %0, %1 clamp")
+DEF(sub_co, "v_sub_co_u32 %0, vcc, %0, %1")
+DEF(subb_co, "v_subbrev_co_u32 %0, vcc, 0, %0, vcc")
+DEF(xor3, "v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96")
+DEF(lshl_add, "v_lshl_add_u32 %0, %0, 3, %1")
+DEF(add_lshl, "v_add_lshl_u32 %0, %0, %1, 3")
+DEF(or3, "v_or3_b32 %0, %0, %1, %2")
 int main() {
     uint32_t* d; hipMalloc(&d, 4 * 256 * 256 * 16);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -98,5 +112,6 @@ int main() {
     RUN(fma_f32) RUN(pk_fma_f16) RUN(pk_max_f16) RUN(mov_dpp)
     RUN(min_f32) RUN(max_f32) RUN(med3_f32) RUN(min3_f32) RUN(add_f32) RUN(add_f32_abs) RUN(sub_f32) RUN(mul_f32) RUN(cvt_f32_ubyte1) RUN(cvt_pk_u8_f32) RUN(cvt_u32_f32) RUN(cvt_f32_i32)
     RUN(cmp_eq_f32_cnd) RUN(cmp_eq_u32_cnd) RUN(cmp_sgpr_cnd) RUN(and_b32) RUN(or_b32) RUN(not_b32) RUN(min_i32) RUN(max_i32) RUN(lshlrev) RUN(lshrrev) RUN(sub_sdwa) RUN(and_sdwa) RUN(mov_b32) RUN(alignbit) RUN(fma_mix) RUN(subrev_f32_neg)
+    RUN(sub_i32_clamp) RUN(add_i32_clamp) RUN(sub_u32_clamp) RUN(add_u32_e64) RUN(lshl_sdwa) RUN(med3_u32) RUN(max3_u32) RUN(add_i16_clamp) RUN(sub_co) RUN(subb_co) RUN(xor3) RUN(lshl_add) RUN(add_lshl) RUN(or3)
     return 0;
 }
