@@ -193,6 +193,7 @@ def main():
     for _ in range(args.warmup):
         step()
     dec.profile(True)  # HIP events around the dominant kernel, on its launch stream
+    kname = dec.kernel_name
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -224,8 +225,8 @@ def main():
             "parity": parity,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": measured_traffic("ldpc_layered_kernel", nf, args.trials) if args.input == "noise" else None,
-                         "kernel": "ldpc_layered_kernel", "avg_launch_ms": avg_kernel_s * 1e3, "launches": launches,
+                         "traffic": measured_traffic(kname, nf, args.trials) if args.input == "noise" else None,
+                         "kernel": kname, "avg_launch_ms": avg_kernel_s * 1e3, "launches": launches,
                          "algorithmic_bytes_per_frame": b_alg},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -192,6 +192,11 @@ int dvbs2_ldpc_decode(dvbs2_ldpc_t* h, const int8_t* llr_in, int n_frames, int m
     API_CATCH
 }
 
+const char* dvbs2_ldpc_kernel_name(const dvbs2_ldpc_t* h)
+{
+    return h ? h->dec->kernel_name() : nullptr;
+}
+
 int dvbs2_ldpc_profile(dvbs2_ldpc_t* h, int enable, double* total_ms, int* launches)
 {
     if (!h) return fail(DVBS2_EINVAL, "null handle");

@@ -21,6 +21,8 @@ public:
     int K() const { return sched_.K; }
     int q() const { return sched_.q; }
     int out_bits_message() const { return out_bits_message_; }
+    // name of the sweep kernel this handle launches (as a profiler shows it, without the argument list)
+    const char* kernel_name() const { return kname_.c_str(); }
     int group_size() const { return G_; }
     int max_frames() const { return max_frames_; }
     const LdpcSchedule& schedule() const { return sched_; }
@@ -47,6 +49,7 @@ private:
     int dmax_ = 0;            // kernel variant: handles check degrees dmax-7 .. dmax (8, 12, ..., 32)
     uint32_t* d_recs_ = nullptr;  // per-layer records (ldpc_hip.hip)
     size_t lds_bytes_ = 0;
+    std::string kname_;
     bool pr_ = false;             // parity-in-records kernel variant selected (ldpc_kernel_pr.hpp)
     unsigned long long* d_tdbg_ = nullptr; // DVBS2_TIMING=1: per-wave cycle-counter breakdown (diagnostics)
     uint8_t* d_state_ = nullptr;  // max_frames * N, internal layout, offset-binary LLRs

@@ -105,7 +105,11 @@ LdpcDecoderHip::LdpcDecoderHip(const LdpcTableDesc* table, int out_bits_message,
     }
     // "parity in records" variant (ldpc_kernel_pr.hpp): check degree <= 7, at most 4 hazard entries per layer, and two
     // pair workgroups must fit the 160 KB of LDS
-    pr_ = dmax_ == 8 && degmax <= 7 && getenv("DVBS2_PR") != nullptr; // opt-in: measured +3 % on table B4, -25 % on B1
+    // Policy (measured on MI355X, tools/pr_sweep.sh; the two variants give identical bits): every eligible short and
+    // medium table gains 12-36 %, normal frames gain where every check has degree 7 (table B4: +10 %) and lose on the
+    // lowest rates with 100+ thin layers (B1, B3, S2X B1-B3: -5..-20 %). DVBS2_PR=0 / 1 overrides.
+    pr_ = dmax_ == 8 && degmax <= 7 && (sched_.N < 64800 || degmin >= 7);
+    if (const char* e = getenv("DVBS2_PR")) pr_ = dmax_ == 8 && degmax <= 7 && atoi(e) != 0;
     for (const LdpcLayer& L : sched_.layers)
         if (L.block < 360 && (L.n_conflict > 4 || (L.n_conflict > 2 ? 4 : 2) > L.cnt)) pr_ = false;
     if (2 * pr_lds_bytes(sched_.N, sched_.K) > 160 * 1024) pr_ = false;
@@ -128,6 +132,7 @@ LdpcDecoderHip::LdpcDecoderHip(const LdpcTableDesc* table, int out_bits_message,
     HIP_OK(hipEventCreate(&ev0_));
     HIP_OK(hipEventCreate(&ev1_));
     if (getenv("DVBS2_TIMING")) { HIP_OK(hipMalloc(&d_tdbg_, (size_t)max_frames_ * 6 * 8 * 8)); HIP_OK(hipMemset(d_tdbg_, 0, (size_t)max_frames_ * 6 * 8 * 8)); }
+    kname_ = pr_ ? std::string("ldpc_layered_pr_kernel") : "ldpc_layered_kernel<" + std::to_string(dmax_) + ">";
     lds_bytes_ = pr_ ? pr_lds_bytes(sched_.N, sched_.K) : 2 * half_lds_bytes(sched_.N);
     if (const char* e = getenv("DVBS2_LDS_PAD")) lds_bytes_ += (size_t)atoi(e); // occupancy experiments only
     if (pr_) HIP_OK(ldpc_pr_prepare(lds_bytes_));

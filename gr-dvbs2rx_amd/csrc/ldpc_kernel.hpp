@@ -46,6 +46,20 @@ __device__ __forceinline__ int mag_offset(int Lb, int mb)
     asm("v_med3_i32 %0, %1, 0, %2" : "=v"(r) : "v"(a), "s"(126));
     return r;
 }
+// LDS address of check row jj for entry (S0 = 360*g + rot, thr = 360 - rot): S0 + jj, minus 360 when jj >= thr.
+// The canonical compare + select + add3 is three half-rate VALU instructions; this is four full-rate ones (2.5 vs 4.3
+// cycles each on gfx950): subtract, sign mask, bitfield select between jj and jj - 360 (v_bitop3), add.
+__device__ __forceinline__ int wrap_addr(int jj, int jj360, uint32_t S0, uint32_t thr)
+{
+    int r;
+    asm("v_subrev_u32 %0, %3, %1\n\t"
+        "v_ashrrev_i32 %0, 31, %0\n\t"
+        "v_bitop3_b32 %0, %0, %1, %2 bitop3:0xca\n\t"
+        "v_add_u32 %0, %4, %0"
+        : "=&v"(r) : "v"(jj), "v"(jj360), "s"(thr), "s"(S0));
+    return r;
+}
+
 // R3: the two smallest of N magnitudes. The kernel is bound by the VALU pipe and min/max/med3 are half-rate
 // there, so the count matters: triples go through v_min3 + v_med3 (smallest and second smallest of three in two
 // instructions), two sorted pairs merge in three, a single value folds in with two -- 9 instructions for seven
@@ -97,12 +111,13 @@ __device__ __forceinline__ void check_node(uint8_t* __restrict__ lds, const uint
     constexpr bool OWN_REG = PR && !LAST;     // entry DEG-2
     constexpr bool PREV_REG = PR && !LAYER0;  // entry DEG-1
     int ad[DEG], Lb[DEG];
+    const int jj360 = jj - kM;
 #pragma unroll
     for (int k = 0; k < DEG; k++) {
         // address = S0 + jj, minus 360 when jj >= thr; the two parity entries have rot = 0 (never wrap) except
         // the previous-parity entry of layer 0 (rot = 359)
         if (k >= DEG - 2 && !(LAYER0 && k == DEG - 1)) ad[k] = jj + (int)ent[2 * k];
-        else ad[k] = jj + (int)ent[2 * k] - ((uint32_t)jj < ent[2 * k + 1] ? 0 : kM);
+        else ad[k] = wrap_addr(jj, jj360, ent[2 * k], ent[2 * k + 1]);
     }
 #pragma unroll
     for (int k = 0; k < DEG; k++) {
@@ -176,6 +191,7 @@ __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, con
     constexpr bool OWN_REG = PR && !LAST;     // entry DEG-2 (see check_node)
     constexpr bool PREV_REG = PR && !LAYER0;  // entry DEG-1
     int ad[DEG], inp[DEG], mg[DEG];
+    const int jj360 = jj - kM;
     int min0 = 127, min1 = 127, signs = 0;
     int spare = 0x80;
     const bool last_valid = !LAYER0 || jj != 0;
@@ -183,7 +199,7 @@ __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, con
 #pragma unroll
         for (int k = 0; k < DEG; k++) {
             if (k >= DEG - 2 && !(LAYER0 && k == DEG - 1)) ad[k] = jj + (int)ent[2 * k];
-            else ad[k] = jj + (int)ent[2 * k] - ((uint32_t)jj < ent[2 * k + 1] ? 0 : kM);
+            else ad[k] = wrap_addr(jj, jj360, ent[2 * k], ent[2 * k + 1]);
         }
 #pragma unroll
         for (int k = 0; k < DEG; k++) {
@@ -572,19 +588,29 @@ template <int DMAX> hipError_t ldpc_variant_prepare(size_t lds_bytes);
 template <int DMAX> void ldpc_variant_launch(const LdpcLaunch& a);
 
 #ifdef DVBS2_LDPC_INSTANTIATE
+// The cycle-stamped variant (DVBS2_TIMING=1, tools/exp_tables.py) is only built for DMAX = 8 -- the headline tables --
+// to keep the build time of the large variants down; elsewhere the request is ignored.
+template <int DMAX> constexpr bool kTimingBuilt = (DMAX == 8);
 template <int DMAX> hipError_t ldpc_variant_prepare(size_t lds_bytes)
 {
     hipError_t e = hipFuncSetAttribute((const void*)ldpc_layered_kernel<DMAX, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return e;
-    return hipFuncSetAttribute((const void*)ldpc_layered_kernel<DMAX, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if constexpr (kTimingBuilt<DMAX>)
+        return hipFuncSetAttribute((const void*)ldpc_layered_kernel<DMAX, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    return hipSuccess;
 }
 template <int DMAX> void ldpc_variant_launch(const LdpcLaunch& a)
 {
     const dim3 grid((a.n_frames + 1) / 2), block(kThreads);
-    if (a.tdbg) hipLaunchKernelGGL((ldpc_layered_kernel<DMAX, true>), grid, block, a.lds_bytes, a.stream, a.recs, a.llr_in, a.state, a.msgs,
-                                   a.iters, a.good, a.target, a.n_frames, a.N, a.K, a.q, a.cap, a.stop_on_good, a.tdbg);
-    else hipLaunchKernelGGL((ldpc_layered_kernel<DMAX, false>), grid, block, a.lds_bytes, a.stream, a.recs, a.llr_in, a.state, a.msgs,
-                            a.iters, a.good, a.target, a.n_frames, a.N, a.K, a.q, a.cap, a.stop_on_good, a.tdbg);
+    if constexpr (kTimingBuilt<DMAX>) {
+        if (a.tdbg) {
+            hipLaunchKernelGGL((ldpc_layered_kernel<DMAX, true>), grid, block, a.lds_bytes, a.stream, a.recs, a.llr_in, a.state, a.msgs,
+                               a.iters, a.good, a.target, a.n_frames, a.N, a.K, a.q, a.cap, a.stop_on_good, a.tdbg);
+            return;
+        }
+    }
+    hipLaunchKernelGGL((ldpc_layered_kernel<DMAX, false>), grid, block, a.lds_bytes, a.stream, a.recs, a.llr_in, a.state, a.msgs,
+                       a.iters, a.good, a.target, a.n_frames, a.N, a.K, a.q, a.cap, a.stop_on_good, nullptr);
 }
 template hipError_t ldpc_variant_prepare<DVBS2_LDPC_INSTANTIATE>(size_t);
 template void ldpc_variant_launch<DVBS2_LDPC_INSTANTIATE>(const LdpcLaunch&);

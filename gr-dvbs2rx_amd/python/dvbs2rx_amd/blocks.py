@@ -134,6 +134,10 @@ class LdpcDecoder:
         check(lib.dvbs2_ldpc_decode_device(self._h, d_llr, n_frames, self.max_trials, self.outputmode,
                                            d_bits, d_llr_out or None, d_ret or None, stream or None))
 
+    @property
+    def kernel_name(self):
+        return lib.dvbs2_ldpc_kernel_name(self._h).decode()
+
     def profile(self, enable=True):
         ms, n = C.c_double(), C.c_int()
         check(lib.dvbs2_ldpc_profile(self._h, 1 if enable else 0, ms, n))

@@ -50,6 +50,7 @@ SYMBOLS = {
     "dvbs2_ldpc_decode": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "dvbs2_ldpc_decode_device": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "dvbs2_ldpc_profile": (_i, [_vp, _i, C.POINTER(C.c_double), _ip]),
+    "dvbs2_ldpc_kernel_name": (C.c_char_p, [_vp]),
     "dvbs2_bch_create": (_i, [C.POINTER(_vp), _i, _i, _i, _i, _i]),
     "dvbs2_bch_create_raw": (_i, [C.POINTER(_vp), _i, C.c_uint32, _i, _i, _i, _i]),
     "dvbs2_bch_destroy": (None, [_vp]),

@@ -99,6 +99,9 @@ int dvbs2_ldpc_decode_device(dvbs2_ldpc_t* h, const int8_t* d_llr_in, int n_fram
 /* HIP-event timing of the dominant kernel (the layered update sweep) on its launch stream.
  * enable != 0 starts/reset accumulation; reads back total milliseconds and launch count. */
 int dvbs2_ldpc_profile(dvbs2_ldpc_t* h, int enable, double* total_ms, int* launches);
+/* which sweep kernel the handle launches, as rocprofv3 names it: "ldpc_layered_kernel<DMAX>" or
+ * "ldpc_layered_pr_kernel" (parity LLRs kept in registers / message records; chosen per table, identical results) */
+const char* dvbs2_ldpc_kernel_name(const dvbs2_ldpc_t* h);
 
 /* ---- BCH: replaces bch_codec<uint32_t, bitset256_t>::decode(u8_cptr_t, u8_ptr_t) as called by
  * bch_decoder_bb_impl (reference lib/bch.h:151, lib/bch_decoder_bb_impl.cc:58-66, :94-113) ----

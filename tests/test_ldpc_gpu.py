@@ -59,10 +59,14 @@ def test_near_threshold_groups(table, amp, sigma, G):
     assert len(ret) == 64 // G
 
 
+@pytest.mark.parametrize("variant", ["policy", "classic"])
 @pytest.mark.parametrize("table", ldpc_table_names())
-def test_every_table_bit_exact(table):
+def test_every_table_bit_exact(table, variant, monkeypatch):
     """All 57 DVB-S2 / S2X / T2 tables of the reference: never-converging input (fixed trip count)
-    and noisy codewords (groups converge at different counts), bit-exact LLRs, bits and return values."""
+    and noisy codewords (groups converge at different counts), bit-exact LLRs, bits and return values -- with the kernel
+    variant the library picks for the table and with the classic kernel forced."""
+    if variant == "classic":
+        monkeypatch.setenv("DVBS2_PR", "0")
     N = T.ldpc_info(table)[0]
     assert compare(table, T.llr_noise(32, N, 777), 32, 3).tolist() == [-1]
     llr, _ = T.llr_codeword_awgn(table, 32, 4242, amp=12, sigma=3.0)
@@ -173,11 +177,13 @@ def test_ragged_and_empty_batches():
         assert ret.tolist() == wret and np.array_equal(out, want)
 
 
-def test_parity_in_records_variant(monkeypatch):
-    """The opt-in kernel variant that keeps parity LLRs in registers / message records (ldpc_kernel_pr.hpp) must give
-    the same bits: near-threshold groups (resume passes), never-converging input, hazard layers, layer 0 / last layer."""
-    monkeypatch.setenv("DVBS2_PR", "1")
-    for table, amp, sigma in (("S2_TABLE_B4", 6, 5.2), ("S2_TABLE_B1", 4, 6.6), ("S2_TABLE_B3", 5, 5.6)):
+@pytest.mark.parametrize("force", ["1", "0"])
+def test_parity_in_records_variant(monkeypatch, force):
+    """Both kernel variants on the tables where the library would pick either one (DVBS2_PR overrides the policy):
+    "parity in records" (ldpc_kernel_pr.hpp, parity LLRs in registers / message records) and the classic kernel must
+    give the same bits: near-threshold groups (resume passes), never-converging input, hazard layers, first / last layer."""
+    monkeypatch.setenv("DVBS2_PR", force)
+    for table, amp, sigma in (("S2_TABLE_B4", 6, 5.2), ("S2_TABLE_B1", 4, 6.6), ("S2_TABLE_B3", 5, 5.6), ("S2_TABLE_C1", 5, 6.5)):
         llr, _ = T.llr_codeword_awgn(table, 64, 99, amp=amp, sigma=sigma)
         compare(table, llr, 32, 50)
         compare(table, llr[:48], 16, 30)
