@@ -49,14 +49,15 @@ __device__ __forceinline__ int mag_offset(int Lb, int mb)
 // LDS address of check row jj for entry (S0 = 360*g + rot, thr = 360 - rot): S0 + jj, minus 360 when jj >= thr.
 // The canonical compare + select + add3 is three half-rate VALU instructions; this is four full-rate ones (2.5 vs 4.3
 // cycles each on gfx950): subtract, sign mask, bitfield select between jj and jj - 360 (v_bitop3), add.
-__device__ __forceinline__ int wrap_addr(int jj, int jj360, uint32_t S0, uint32_t thr)
+__device__ __forceinline__ int wrap_addr(int jj, int jjb, int jjb360, uint32_t S0, uint32_t thr)
 {
+    // jjb = jj + byte offset of this frame's LDS region (folded in here: no separate base add per access)
     int r;
-    asm("v_subrev_u32 %0, %3, %1\n\t"
+    asm("v_subrev_u32 %0, %4, %1\n\t"
         "v_ashrrev_i32 %0, 31, %0\n\t"
-        "v_bitop3_b32 %0, %0, %1, %2 bitop3:0xca\n\t"
-        "v_add_u32 %0, %4, %0"
-        : "=&v"(r) : "v"(jj), "v"(jj360), "s"(thr), "s"(S0));
+        "v_bitop3_b32 %0, %0, %2, %3 bitop3:0xca\n\t"
+        "v_add_u32 %0, %5, %0"
+        : "=&v"(r) : "v"(jj), "v"(jjb), "v"(jjb360), "s"(thr), "s"(S0));
     return r;
 }
 
@@ -85,6 +86,14 @@ __device__ __forceinline__ void two_smallest(const int* v, int& m0, int& m1)
     for (; k < N; k++) { m1 = vmed3_i32(m0, m1, v[k]); m0 = min(m0, v[k]); }
 }
 
+// R2 without its clamp: |Lb - mb| - 1 in [-1, 254]. Clamping to [0, 126] is monotone, so the two smallest clamped
+// magnitudes are the clamps of the two smallest raw ones (two v_med3 per check instead of one per edge), and the
+// selection "mag == min0 ? min1 : min0" becomes min0 + min1 - med3(raw, min0, min1): clamping raw into
+// [min0, min1] gives min0 exactly when the clamped magnitude is the smallest one.
+__device__ __forceinline__ int mag_raw(int Lb, int mb) { return (int)__builtin_amdgcn_sad_u16((uint32_t)Lb, (uint32_t)mb, 0xffffffffu); }
+__device__ __forceinline__ int clamp_mag(int x) { int r; asm("v_med3_i32 %0, %1, 0, %2" : "=v"(r) : "v"(x), "s"(126)); return r; }
+constexpr int kMagAbsent = 0x7fff; // a link that does not exist (check (0,0)): above every raw magnitude
+
 // low bytes of four 32-bit values -> one dword (two v_perm_b32 + or)
 __device__ __forceinline__ uint32_t pack4_lo8(int a, int b, int c, int d)
 {
@@ -105,19 +114,20 @@ __device__ __forceinline__ uint32_t pack4_lo8(int a, int b, int c, int d)
 // LLR is returned in byte 7 of this layer's record. Only row q-1 (own parity of the LAST layer, previous
 // parity of layer 0 shifted by one lane) stays in LDS.
 template <int DEG, bool LAYER0, bool PR = false, bool LAST = false>
-__device__ __forceinline__ void check_node(uint8_t* __restrict__ lds, const uint32_t* ent /*uniform: S0, thr pairs*/,
-                                           int jj, const uint32_t* mw, uint32_t* nm, int own_in = 0, int* carry = nullptr)
+__device__ __forceinline__ void check_node(uint8_t* __restrict__ lds /*the whole LDS array*/, const uint32_t* ent /*uniform: S0, thr pairs*/,
+                                           int jj, int lb /*byte offset of this frame's region*/, const uint32_t* mw, uint32_t* nm,
+                                           int own_in = 0, int* carry = nullptr)
 {
     constexpr bool OWN_REG = PR && !LAST;     // entry DEG-2
     constexpr bool PREV_REG = PR && !LAYER0;  // entry DEG-1
     int ad[DEG], Lb[DEG];
-    const int jj360 = jj - kM;
+    const int jjb = jj + lb, jjb360 = jjb - kM;
 #pragma unroll
     for (int k = 0; k < DEG; k++) {
         // address = S0 + jj, minus 360 when jj >= thr; the two parity entries have rot = 0 (never wrap) except
         // the previous-parity entry of layer 0 (rot = 359)
-        if (k >= DEG - 2 && !(LAYER0 && k == DEG - 1)) ad[k] = jj + (int)ent[2 * k];
-        else ad[k] = wrap_addr(jj, jj360, ent[2 * k], ent[2 * k + 1]);
+        if (k >= DEG - 2 && !(LAYER0 && k == DEG - 1)) ad[k] = jjb + (int)ent[2 * k];
+        else ad[k] = wrap_addr(jj, jjb, jjb360, ent[2 * k], ent[2 * k + 1]);
     }
 #pragma unroll
     for (int k = 0; k < DEG; k++) {
@@ -136,12 +146,13 @@ __device__ __forceinline__ void check_node(uint8_t* __restrict__ lds, const uint
         const int mb = (int)((mw[k >> 2] >> (8 * (k & 3))) & 0xffu);
         // R1 inp = sat8(L - m); R2 mag = usat(qabs(inp) - 1) == med3(|L - m| - 1, 0, 126)
         int d = min(max(Lb[k] - mb, -128), 127);
-        int mag = mag_offset(Lb[k], mb);
-        if (LAYER0 && k == DEG - 1) { d = last_valid ? d : 0; mag = last_valid ? mag : 127; }
+        int mag = mag_raw(Lb[k], mb);
+        if (LAYER0 && k == DEG - 1) { d = last_valid ? d : 0; mag = last_valid ? mag : kMagAbsent; }
         inp[k] = d; mg[k] = mag;
         signs ^= d; // R4 xor of the sign bits
     }
-    two_smallest<DEG>(mg, min0, min1); // R3
+    two_smallest<DEG>(mg, min0, min1); // R3 on raw magnitudes; R2's clamp once per check
+    min0 = clamp_mag(min0); min1 = clamp_mag(min1);
     const int s01 = min0 + min1;
     int msgc[4 * ((DEG + 3) / 4)];
 #pragma unroll
@@ -150,7 +161,7 @@ __device__ __forceinline__ void check_node(uint8_t* __restrict__ lds, const uint
     for (int k = 0; k < DEG; k++) {
         // R5 out = vsign(mag == min0 ? min1 : min0, (signs ^ x) | 127); mag is min0 or >= min1, so the selected
         // magnitude is min0 + min1 - min(mag, min1)
-        const int other = s01 - min(mg[k], min1);
+        const int other = s01 - vmed3_i32(mg[k], min0, min1);
         const int sg = (signs ^ inp[k]) >> 31;
         const int out = (other ^ sg) - sg;
         // R6 LLR = sat8(inp + out) with the unclamped out; R7 stored message = clamp(out, -32, 31)
@@ -185,21 +196,21 @@ __device__ __forceinline__ void check_node(uint8_t* __restrict__ lds, const uint
 constexpr int kMaxHazard = 8;
 constexpr int kHazardWalk = 15; // header code: too many hazard entries, fall back to the single-wave chunk walk
 template <int DEG, int NC, bool LAYER0, bool PR = false, bool LAST = false>
-__device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, const uint32_t* ent, int jj, bool work,
+__device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, const uint32_t* ent, int jj, int lb, bool work,
                                                   int block, const uint32_t* mw, uint32_t* nm, int own_in = 0, int* carry = nullptr)
 {
     constexpr bool OWN_REG = PR && !LAST;     // entry DEG-2 (see check_node)
     constexpr bool PREV_REG = PR && !LAYER0;  // entry DEG-1
     int ad[DEG], inp[DEG], mg[DEG];
-    const int jj360 = jj - kM;
+    const int jjb = jj + lb, jjb360 = jjb - kM;
     int min0 = 127, min1 = 127, signs = 0;
     int spare = 0x80;
     const bool last_valid = !LAYER0 || jj != 0;
     if (work) {
 #pragma unroll
         for (int k = 0; k < DEG; k++) {
-            if (k >= DEG - 2 && !(LAYER0 && k == DEG - 1)) ad[k] = jj + (int)ent[2 * k];
-            else ad[k] = wrap_addr(jj, jj360, ent[2 * k], ent[2 * k + 1]);
+            if (k >= DEG - 2 && !(LAYER0 && k == DEG - 1)) ad[k] = jjb + (int)ent[2 * k];
+            else ad[k] = wrap_addr(jj, jjb, jjb360, ent[2 * k], ent[2 * k + 1]);
         }
 #pragma unroll
         for (int k = 0; k < DEG; k++) {
@@ -207,13 +218,14 @@ __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, con
                 const int Lb = (OWN_REG && k == DEG - 2) ? own_in : (PREV_REG && k == DEG - 1) ? *carry : (int)lds[ad[k]];
                 const int mb = (int)((mw[k >> 2] >> (8 * (k & 3))) & 0xffu);
                 int d = min(max(Lb - mb, -128), 127);
-                int mag = mag_offset(Lb, mb);
-                if (LAYER0 && k == DEG - 1) { d = last_valid ? d : 0; mag = last_valid ? mag : 127; }
+                int mag = mag_raw(Lb, mb);
+                if (LAYER0 && k == DEG - 1) { d = last_valid ? d : 0; mag = last_valid ? mag : kMagAbsent; }
                 inp[k] = d; mg[k] = mag;
                 signs ^= d;
             }
         }
-        two_smallest<DEG - NC>(mg + NC, min0, min1);
+        two_smallest<DEG - NC>(mg + NC, min0, min1); // raw magnitudes of the regular entries (see mag_raw)
+        min0 = clamp_mag(min0); min1 = clamp_mag(min1);
     }
 #pragma unroll
     for (int w = 0; w < (DEG + 3) / 4; w++) nm[w] = 0;
@@ -270,7 +282,7 @@ __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, con
 #pragma unroll
         for (int k = 0; k < DEG; k++) {
             if (k >= NC) {
-                const int other = s01 - min(mg[k], min1);
+                const int other = s01 - vmed3_i32(mg[k], min0, min1); // regular entries hold raw magnitudes
                 const int sg = (signs ^ inp[k]) >> 31;
                 const int out = (other ^ sg) - sg;
                 const int nl = sat_sum_u8(inp[k], out);
@@ -286,7 +298,7 @@ __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, con
 
 // degrees DMAX-7 .. DMAX are instantiated for kernel variant DMAX
 #define DVBS2_DEG_CASE(D) case D: if constexpr (D >= 3 && D <= DMAX && D > DMAX - 8) { \
-        if (layer0) check_node<(D >= 3 ? D : 3), true>(lds, ent, jj, mw, nm); else check_node<(D >= 3 ? D : 3), false>(lds, ent, jj, mw, nm); } break;
+        if (layer0) check_node<(D >= 3 ? D : 3), true>(lds_all, ent, jj, lb, mw, nm); else check_node<(D >= 3 ? D : 3), false>(lds_all, ent, jj, lb, mw, nm); } break;
 #define DVBS2_DEG_SWITCH switch (deg) { \
         DVBS2_DEG_CASE(3) DVBS2_DEG_CASE(4) DVBS2_DEG_CASE(5) DVBS2_DEG_CASE(6) DVBS2_DEG_CASE(7) DVBS2_DEG_CASE(8) \
         DVBS2_DEG_CASE(9) DVBS2_DEG_CASE(10) DVBS2_DEG_CASE(11) DVBS2_DEG_CASE(12) DVBS2_DEG_CASE(13) DVBS2_DEG_CASE(14) \
@@ -296,7 +308,7 @@ __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, con
         default: break; }
 
 #define DVBS2_HAZ_CALL(D, NCV) { if constexpr (D - 2 >= NCV) { \
-        if (layer0) check_node_hazard<D, NCV, true>(lds, ent, jj, work, block, mw, nm); else check_node_hazard<D, NCV, false>(lds, ent, jj, work, block, mw, nm); } }
+        if (layer0) check_node_hazard<D, NCV, true>(lds_all, ent, jj, lb, work, block, mw, nm); else check_node_hazard<D, NCV, false>(lds_all, ent, jj, lb, work, block, mw, nm); } }
 #define DVBS2_HAZ_CASE(D) case D: if constexpr (D >= 4 && D <= DMAX && D > DMAX - 8) { \
         if (nc == 2) DVBS2_HAZ_CALL((D >= 4 ? D : 4), 2) else if (nc == 4) DVBS2_HAZ_CALL((D >= 4 ? D : 4), 4) else DVBS2_HAZ_CALL((D >= 4 ? D : 4), 8) } break;
 #define DVBS2_HAZ_SWITCH switch (deg) { \
@@ -322,7 +334,8 @@ __global__ __launch_bounds__(kThreads) void ldpc_layered_kernel(
     constexpr int MW = DMAX / 4; // message dwords per check (fixed per kernel variant)
     const int half = __builtin_amdgcn_readfirstlane(threadIdx.x >= kHalf ? 1 : 0); // wave-uniform, and the compiler knows it
     const int tid = threadIdx.x - half * kHalf;
-    uint8_t* lds = lds_all + half * half_lds_bytes(N);
+    const int lb = half * (int)half_lds_bytes(N);
+    uint8_t* lds = lds_all + lb;
     uint32_t* sv = reinterpret_cast<uint32_t*>(lds + N); // N % 8 == 0
     volatile int* flags = reinterpret_cast<volatile int*>(sv + (N / kM) * kSvWords); // [0] bad-or, [1] finished, [2] pre-test failed, [3] full test needed
     volatile int* other_flags = reinterpret_cast<volatile int*>(

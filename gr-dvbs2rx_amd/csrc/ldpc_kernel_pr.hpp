@@ -24,14 +24,14 @@ __host__ __device__ constexpr size_t pr_lds_bytes(int N, int K) { return 2 * pr_
 
 #ifdef DVBS2_LDPC_INSTANTIATE_PR
 #define DVBS2_PR_CASE(D) case D: { \
-        if (first_layer) check_node<D, true, true, false>(lds, ent, jj, mw, nm, own_in, &carry); \
-        else if (last_layer) check_node<D, false, true, true>(lds, ent, jj, mw, nm, own_in, &carry); \
-        else check_node<D, false, true, false>(lds, ent, jj, mw, nm, own_in, &carry); } break;
+        if (first_layer) check_node<D, true, true, false>(lds_all, ent, jj, lb, mw, nm, own_in, &carry); \
+        else if (last_layer) check_node<D, false, true, true>(lds_all, ent, jj, lb, mw, nm, own_in, &carry); \
+        else check_node<D, false, true, false>(lds_all, ent, jj, lb, mw, nm, own_in, &carry); } break;
 #define DVBS2_PR_SWITCH switch (deg) { DVBS2_PR_CASE(3) DVBS2_PR_CASE(4) DVBS2_PR_CASE(5) DVBS2_PR_CASE(6) DVBS2_PR_CASE(7) default: break; }
 #define DVBS2_PRH_CALL(D, NCV) { if constexpr (D - 2 >= NCV) { \
-        if (first_layer) check_node_hazard<D, NCV, true, true, false>(lds, ent, jj, work, block, mw, nm, own_in, &carry); \
-        else if (last_layer) check_node_hazard<D, NCV, false, true, true>(lds, ent, jj, work, block, mw, nm, own_in, &carry); \
-        else check_node_hazard<D, NCV, false, true, false>(lds, ent, jj, work, block, mw, nm, own_in, &carry); } }
+        if (first_layer) check_node_hazard<D, NCV, true, true, false>(lds_all, ent, jj, lb, work, block, mw, nm, own_in, &carry); \
+        else if (last_layer) check_node_hazard<D, NCV, false, true, true>(lds_all, ent, jj, lb, work, block, mw, nm, own_in, &carry); \
+        else check_node_hazard<D, NCV, false, true, false>(lds_all, ent, jj, lb, work, block, mw, nm, own_in, &carry); } }
 #define DVBS2_PRH_CASE(D) case D: { if (nc == 2) DVBS2_PRH_CALL(D, 2) else if (nc == 4) DVBS2_PRH_CALL(D, 4) } break;
 #define DVBS2_PRH_SWITCH switch (deg) { DVBS2_PRH_CASE(4) DVBS2_PRH_CASE(5) DVBS2_PRH_CASE(6) DVBS2_PRH_CASE(7) default: break; }
 
@@ -46,7 +46,8 @@ __global__ __launch_bounds__(kThreads, 6) void ldpc_layered_pr_kernel(
     constexpr int DMAX = 8, RS = rec_stride(DMAX), MW = 2;
     const int half = __builtin_amdgcn_readfirstlane(threadIdx.x >= kHalf ? 1 : 0);
     const int tid = threadIdx.x - half * kHalf;
-    uint8_t* lds = lds_all + half * pr_half_bytes(K);
+    const int lb = half * (int)pr_half_bytes(K);
+    uint8_t* lds = lds_all + lb;
     uint32_t* sv = reinterpret_cast<uint32_t*>(lds_all + 2 * pr_half_bytes(K));
     volatile int* flags_all = reinterpret_cast<volatile int*>(sv + (N / kM) * kSvWords);
     volatile int* flags = flags_all + 8 * half;        // [0] bad-or, [1] finished, [2] pre-test failed, [3] full test needed
