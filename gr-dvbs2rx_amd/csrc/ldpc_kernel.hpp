@@ -234,20 +234,40 @@ __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, con
     // other hazard magnitudes) and the sign is the xor of all other signs; the merge of the hazard entries into
     // (min0, min1, signs) for P3 and the hazard message bytes are computed after the loop.
     if (PR && (DEG + 3) / 4 < 2) nm[1] = 0;
-    int hout[NC];
+    int hout[NC], hmb[NC];
 #pragma unroll
-    for (int k = 0; k < NC; k++) { hout[k] = 0; inp[k] = 0; mg[k] = 127; }
-    for (int start = 0; start < kM; start += block) {
-        if (work && jj >= start && jj < start + block) {
+    for (int k = 0; k < NC; k++) { hout[k] = 0; inp[k] = 0; mg[k] = 127; hmb[k] = (int)((mw[k >> 2] >> (8 * (k & 3))) & 0xffu); }
+    // One ordered step per block of `block` rows. A step is a chain of dependent instructions of a single wave (the
+    // next block reads what this one wrote), so its length is what a hazard layer costs: rel = jj - start is kept
+    // incrementally (one subtract + one unsigned compare select the rows of the block).
+    int rel = work ? jj : 0x40000000;
+    for (int start = 0; start < kM; start += block, rel -= block) {
+        if ((uint32_t)rel < (uint32_t)block) {
+            if constexpr (NC == 2) {
+                // two hazard entries: each one's magnitude sent back is min(partial min0, the other's magnitude) =
+                // med3(raw other, 0, min0) (min0 is already clamped to [0, 126])
+                const int L0 = lds[ad[0]], L1 = lds[ad[1]];
+                inp[0] = min(max(L0 - hmb[0], -128), 127);
+                inp[1] = min(max(L1 - hmb[1], -128), 127);
+                mg[0] = mag_raw(L0, hmb[0]);
+                mg[1] = mag_raw(L1, hmb[1]);
+                int o0, o1;
+                asm("v_med3_i32 %0, %1, 0, %2" : "=v"(o0) : "v"(mg[1]), "v"(min0));
+                asm("v_med3_i32 %0, %1, 0, %2" : "=v"(o1) : "v"(mg[0]), "v"(min0));
+                const int s0 = (signs ^ inp[1]) >> 31, s1 = (signs ^ inp[0]) >> 31;
+                hout[0] = (o0 ^ s0) - s0;
+                hout[1] = (o1 ^ s1) - s1;
+                lds[ad[0]] = (uint8_t)sat_sum_u8(inp[0], hout[0]);
+                lds[ad[1]] = (uint8_t)sat_sum_u8(inp[1], hout[1]);
+            } else {
             int Lh[NC];
 #pragma unroll
             for (int k = 0; k < NC; k++) Lh[k] = lds[ad[k]];
             int xall = signs;
 #pragma unroll
             for (int k = 0; k < NC; k++) {
-                const int mb = (int)((mw[k >> 2] >> (8 * (k & 3))) & 0xffu);
-                inp[k] = min(max(Lh[k] - mb, -128), 127);
-                mg[k] = mag_offset(Lh[k], mb);
+                inp[k] = min(max(Lh[k] - hmb[k], -128), 127);
+                mg[k] = mag_offset(Lh[k], hmb[k]);
                 xall ^= inp[k];
             }
             int pre[NC + 1], suf[NC + 1]; // pre[k] = min(min0, mg[0..k)), suf[k] = min(mg[k..NC))
@@ -264,12 +284,14 @@ __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, con
                 hout[k] = out;
                 lds[ad[k]] = (uint8_t)sat_sum_u8(inp[k], out);
             }
+            }
         }
         // the next block reads what this one wrote: a workgroup barrier, unless both blocks sit inside one and the
         // same wavefront (LDS operations of a wave execute in program order)
         if ((start >> 6) != ((start + 2 * block - 1) >> 6)) __syncthreads();
     }
     __syncthreads();
+    if constexpr (NC == 2) { mg[0] = clamp_mag(mg[0]); mg[1] = clamp_mag(mg[1]); } // raw in the loop (127 where no step ran: idle rows)
 #pragma unroll
     for (int k = 0; k < NC; k++) {
         min1 = min(max(mg[k], min0), min1);
