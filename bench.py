@@ -227,7 +227,8 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": measured_traffic(kname, nf, args.trials) if args.input == "noise" else None,
                          "kernel": kname, "avg_launch_ms": avg_kernel_s * 1e3, "launches": launches,
-                         "algorithmic_bytes_per_frame": b_alg},
+                         "algorithmic_bytes_per_frame": b_alg,
+                         "limiter": "VALU pipe (half-rate min/med3/sad/add3), not HBM: DESIGN.md 3.3"},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(table, N, args.trials)

@@ -193,3 +193,57 @@ def test_parity_in_records_variant(monkeypatch, force):
         b, rb = T.oracle_ldpc_decode(table, llr[32:33], 1, 30)
         assert ret.tolist() == ra + rb and np.array_equal(out, np.concatenate([a, b]))
         compare(table, T.llr_noise(32, T.ldpc_info(table)[0], 5), 32, 4)
+
+
+def test_kernel_variant_policy(monkeypatch):
+    """Which sweep kernel a handle launches (dvbs2_ldpc_kernel_name): parity-in-records for short/medium frames and
+    for normal frames whose checks all have degree 7; the classic variant of the table's degree class otherwise."""
+    def name(table, **env):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        K = T.ldpc_info(table)[1]
+        dec = LdpcDecoder(table=table, message_bits=K, group_size=32, max_frames=32, max_trials=5)
+        n = dec.kernel_name
+        dec.close()
+        for k in env:
+            monkeypatch.delenv(k)
+        return n
+    assert name("S2_TABLE_B4") == "ldpc_layered_pr_kernel"
+    assert name("S2_TABLE_C1") == "ldpc_layered_pr_kernel"
+    assert name("S2_TABLE_B1") == "ldpc_layered_kernel<8>"       # 135 thin layers: the classic kernel is faster
+    assert name("S2_TABLE_B7") == "ldpc_layered_kernel<16>"
+    assert name("S2_TABLE_B11") == "ldpc_layered_kernel<32>"
+    assert name("S2_TABLE_B4", DVBS2_PR="0") == "ldpc_layered_kernel<8>"
+    assert name("S2_TABLE_B1", DVBS2_PR="1") == "ldpc_layered_pr_kernel"
+
+
+@pytest.mark.parametrize("table,nf,trials,amp,sigma", [("S2_TABLE_B4", 4096, 50, 6, 4.6), ("S2_TABLE_C1", 16384, 25, 5, 4.0)])
+def test_full_batch_properties(table, nf, trials, amp, sigma):
+    """BASELINE.json batch sizes (4096 normal / 16384 short frames per GPU), checked through size-independent properties:
+    encode -> noise -> decode round trip for every frame, idempotence (decoding the decoded LLRs needs 0 updates and
+    changes nothing), independence of the batch size (a 64-frame slice decoded alone gives the same bytes and group
+    results), and that slice against the CPU reference."""
+    N, K, _, _ = T.ldpc_info(table)
+    rng = np.random.default_rng(2024)
+    base = 64
+    info = rng.integers(0, 2, (base, K), dtype=np.uint8)
+    cw = T.ldpc_encode(table, info)
+    reps = nf // base
+    y = amp * (1.0 - 2.0 * cw.astype(np.float32))
+    llr = np.empty((nf, N), np.int8)
+    for r in range(reps):  # same codewords, fresh noise per repetition
+        llr[r * base:(r + 1) * base] = np.clip(np.rint(y + sigma * rng.standard_normal((base, N), dtype=np.float32)), -128, 127)
+    dec = LdpcDecoder(table=table, message_bits=K, group_size=32, max_frames=nf, max_trials=trials, outputmode=capi.OM_CODEWORD)
+    bits, out, ret = dec.work(llr, want_llr=True)
+    assert (ret >= 0).all() and ret.max() < trials          # every group converged after at least one update
+    want_bits = np.packbits(cw, axis=1)
+    assert np.array_equal(bits.reshape(reps, base, -1), np.broadcast_to(want_bits, (reps, base, N // 8)))
+    bits2, out2, ret2 = dec.work(out, want_llr=True)          # idempotence
+    assert (ret2 == trials).all() and np.array_equal(bits2, bits) and np.array_equal(out2, out)
+    lo = 5 * base
+    b3, o3, r3 = dec.work(llr[lo:lo + base], want_llr=True)   # batch-size independence
+    assert np.array_equal(b3, bits[lo:lo + base]) and np.array_equal(o3, out[lo:lo + base])
+    assert r3.tolist() == ret[lo // 32:(lo + base) // 32].tolist()
+    want, wret = checker(table, llr[lo:lo + base], 32, trials)
+    assert np.array_equal(o3, want) and r3.tolist() == wret
+    dec.close()
