@@ -17,7 +17,7 @@ except ImportError:  # standalone use (e.g. from the GNU Radio blocks): the syst
     pass
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.normpath(os.path.join(_HERE, "..", "..", "lib", "libdvbs2_fec_hip.so"))
+LIB_PATH = os.environ.get("DVBS2_LIB") or os.path.normpath(os.path.join(_HERE, "..", "..", "lib", "libdvbs2_fec_hip.so"))  # DVBS2_LIB: kernel experiments
 
 OK, EINVAL, EDEVICE, ESIZE = 0, -1, -2, -3
 STANDARD_DVBS2, STANDARD_DVBT2 = 0, 1
