@@ -9,6 +9,7 @@
 #include "ldpc_schedule.h"
 #include "bch_hip.h"
 #include "demap_hip.h"
+#include "plpayload_hip.h"
 
 using namespace dvbs2;
 
@@ -555,6 +556,107 @@ int dvbs2_chain_decode_device(dvbs2_chain_t* h, const float* d_syms, int n_frame
     if (rc == DVBS2_OK) rc = dvbs2_ldpc_decode_device(h->ldpc, h->d_llr, n_frames, max_trials, DVBS2_OM_MESSAGE, h->d_bits, nullptr, d_ldpc_ret, stream);
     if (rc == DVBS2_OK) rc = dvbs2_bch_decode_device(h->bch, h->d_bits, n_frames, d_msg, d_bch_corr ? d_bch_corr : h->d_corr, stream);
     return rc;
+    API_CATCH
+}
+
+} // extern "C"
+
+/* ------------------------------------------------------------------ PLFRAME payload step */
+struct dvbs2_plpayload {
+    PlPayloadHip* pp = nullptr;
+    float* d_in = nullptr; float* d_out = nullptr; float* d_par = nullptr; int32_t* d_cc = nullptr;
+    hipStream_t stream = nullptr;
+    int device = 0;
+};
+
+extern "C" {
+
+int dvbs2_pl_scrambling_rn(int gold_code, uint8_t* rn, int n)
+{
+    API_TRY
+    if (!rn || n < 0 || n > 360 * 90 + 22 * 36 || gold_code < 0 || gold_code >= (1 << 18) - 1) return fail(DVBS2_EINVAL, "bad argument");
+    pl_scrambling_rn(gold_code, rn, n);
+    return DVBS2_OK;
+    API_CATCH
+}
+
+int dvbs2_plpayload_create(dvbs2_plpayload_t** h, int gold_code, int n_slots, int has_pilots, int max_frames, int device)
+{
+    API_TRY
+    if (!h) return fail(DVBS2_EINVAL, "null handle pointer");
+    *h = nullptr;
+    if (int rc = check_device(device)) return rc;
+    dvbs2_plpayload* o = new (std::nothrow) dvbs2_plpayload();
+    if (!o) return fail(DVBS2_EDEVICE, "out of memory");
+    o->device = device;
+    o->pp = new (std::nothrow) PlPayloadHip(gold_code, n_slots, has_pilots, max_frames, device);
+    if (!o->pp || !o->pp->ok()) { std::string msg = o->pp ? o->pp->error() : "out of memory"; delete o->pp; delete o; return fail(DVBS2_EINVAL, msg); }
+    *h = o;
+    return DVBS2_OK;
+    API_CATCH
+}
+
+void dvbs2_plpayload_destroy(dvbs2_plpayload_t* h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    (void)hipFree(h->d_in); (void)hipFree(h->d_out); (void)hipFree(h->d_par); (void)hipFree(h->d_cc);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h->pp;
+    delete h;
+}
+
+int dvbs2_plpayload_params(const dvbs2_plpayload_t* h, int* payload_len, int* xfecframe_len, int* n_pilots)
+{
+    if (!h) return fail(DVBS2_EINVAL, "null handle");
+    if (payload_len) *payload_len = h->pp->payload_len();
+    if (xfecframe_len) *xfecframe_len = h->pp->xfecframe_len();
+    if (n_pilots) *n_pilots = h->pp->n_pilots();
+    return DVBS2_OK;
+}
+
+int dvbs2_plpayload_process_device(dvbs2_plpayload_t* h, const float* d_payload, int n_frames, const float* d_plheader_phase,
+                                   const float* d_phase_inc, const int32_t* d_coarse_corrected, const float* d_pilot_phase,
+                                   float* d_xfecframes, void* stream)
+{
+    API_TRY
+    if (!h) return fail(DVBS2_EINVAL, "null handle");
+    if (n_frames < 0 || (n_frames && (!d_payload || !d_plheader_phase || !d_phase_inc || !d_coarse_corrected || !d_xfecframes ||
+                                      (h->pp->n_pilots() > 0 && !d_pilot_phase)))) return fail(DVBS2_EINVAL, "bad argument");
+    if (n_frames > h->pp->max_frames()) return fail(DVBS2_ESIZE, "n_frames exceeds max_frames");
+    if (h->pp->process_device(d_payload, n_frames, d_plheader_phase, d_phase_inc, d_coarse_corrected, d_pilot_phase, d_xfecframes,
+                              (hipStream_t)stream)) return fail(DVBS2_EDEVICE, h->pp->error());
+    return DVBS2_OK;
+    API_CATCH
+}
+
+int dvbs2_plpayload_process(dvbs2_plpayload_t* h, const float* payload, int n_frames, const float* plheader_phase, const float* phase_inc,
+                            const int32_t* coarse_corrected, const float* pilot_phase, float* xfecframes)
+{
+    API_TRY
+    if (!h) return fail(DVBS2_EINVAL, "null handle");
+    const int np = h->pp->n_pilots();
+    if (n_frames < 0 || (n_frames && (!payload || !plheader_phase || !phase_inc || !coarse_corrected || !xfecframes || (np > 0 && !pilot_phase))))
+        return fail(DVBS2_EINVAL, "bad argument");
+    if (n_frames > h->pp->max_frames()) return fail(DVBS2_ESIZE, "n_frames exceeds max_frames");
+    if (n_frames == 0) return DVBS2_OK;
+    HCHK(hipSetDevice(h->device));
+    const size_t mf = h->pp->max_frames(), pl = h->pp->payload_len(), xl = h->pp->xfecframe_len(), nf = n_frames;
+    if (!h->stream) HCHK(hipStreamCreate(&h->stream));
+    if (!h->d_in) HCHK(hipMalloc(&h->d_in, mf * pl * 8));
+    if (!h->d_out) HCHK(hipMalloc(&h->d_out, mf * xl * 8));
+    if (!h->d_par) HCHK(hipMalloc(&h->d_par, mf * (2 + (np ? np : 1)) * 4));
+    if (!h->d_cc) HCHK(hipMalloc(&h->d_cc, mf * 4));
+    float* d_hph = h->d_par; float* d_inc = h->d_par + mf; float* d_pp = h->d_par + 2 * mf;
+    HCHK(hipMemcpyAsync(h->d_in, payload, nf * pl * 8, hipMemcpyHostToDevice, h->stream));
+    HCHK(hipMemcpyAsync(d_hph, plheader_phase, nf * 4, hipMemcpyHostToDevice, h->stream));
+    HCHK(hipMemcpyAsync(d_inc, phase_inc, nf * 4, hipMemcpyHostToDevice, h->stream));
+    HCHK(hipMemcpyAsync(h->d_cc, coarse_corrected, nf * 4, hipMemcpyHostToDevice, h->stream));
+    if (np) HCHK(hipMemcpyAsync(d_pp, pilot_phase, nf * np * 4, hipMemcpyHostToDevice, h->stream));
+    if (h->pp->process_device(h->d_in, n_frames, d_hph, d_inc, h->d_cc, d_pp, h->d_out, h->stream)) return fail(DVBS2_EDEVICE, h->pp->error());
+    HCHK(hipMemcpyAsync(xfecframes, h->d_out, nf * xl * 8, hipMemcpyDeviceToHost, h->stream));
+    HCHK(hipStreamSynchronize(h->stream));
+    return DVBS2_OK;
     API_CATCH
 }
 

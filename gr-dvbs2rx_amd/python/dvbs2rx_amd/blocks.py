@@ -14,7 +14,8 @@ from . import capi
 from .capi import lib, check
 
 __all__ = ["get_fec_info", "rate_id", "LdpcDecoder", "BchDecoder", "Demapper", "FecChain", "ldpc_table_info", "ldpc_layer_info",
-           "ldpc_table_names", "bb_descramble_sequence"]
+           "ldpc_table_names", "bb_descramble_sequence", "PlPayload",
+           "pl_scrambling_rn"]
 
 DEFAULT_TRIALS = 25  # reference lib/ldpc_decoder_bb_impl.cc:391
 
@@ -247,6 +248,49 @@ class Demapper:
 
     def work_device(self, d_syms, n_frames, d_n0, n0_count, d_llr, stream=0):
         check(lib.dvbs2_demap_soft_device(self._h, d_syms, n_frames, d_n0, n0_count, d_llr, stream or None))
+
+
+class PlPayload:
+    """PLFRAME payload step of the PL synchroniser (reference lib/plsync_cc_impl.cc:644-653, :727-795): descramble,
+    drop the pilot blocks, de-rotate; produces the XFECFRAME symbols the demapper consumes."""
+
+    def __init__(self, gold_code=0, n_slots=360, has_pilots=True, max_frames=16, device=0):
+        self._h = C.c_void_p()
+        check(lib.dvbs2_plpayload_create(C.byref(self._h), gold_code, n_slots, int(bool(has_pilots)), max_frames, device))
+        v = [C.c_int() for _ in range(3)]
+        check(lib.dvbs2_plpayload_params(self._h, *v))
+        self.payload_len, self.xfecframe_len, self.n_pilots = (x.value for x in v)
+
+    def close(self):
+        if self._h:
+            lib.dvbs2_plpayload_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def work(self, payload, plheader_phase, fine_foffset, coarse_corrected, pilot_phase=None):
+        """payload: (n_frames, payload_len) complex64; per-frame arrays as in plframe_info_t / pl_freq_sync."""
+        payload = np.ascontiguousarray(payload, dtype=np.complex64)
+        nf = payload.shape[0]
+        assert payload.shape == (nf, self.payload_len)
+        hph = np.ascontiguousarray(plheader_phase, np.float32)
+        cc = np.ascontiguousarray(coarse_corrected, np.int32)
+        inc = np.ascontiguousarray(2.0 * np.pi * np.asarray(fine_foffset, np.float64), np.float32)  # :730-731
+        pp = np.ascontiguousarray(pilot_phase if pilot_phase is not None else np.zeros((nf, max(self.n_pilots, 1))), np.float32)
+        out = np.empty((nf, self.xfecframe_len), np.complex64)
+        check(lib.dvbs2_plpayload_process(self._h, payload.ctypes.data, nf, hph.ctypes.data, inc.ctypes.data, cc.ctypes.data,
+                                          pp.ctypes.data, out.ctypes.data))
+        return out
+
+
+def pl_scrambling_rn(gold_code, n):
+    rn = np.zeros(n, np.uint8)
+    check(lib.dvbs2_pl_scrambling_rn(gold_code, rn.ctypes.data, n))
+    return rn
 
 
 class FecChain:

@@ -69,6 +69,12 @@ SYMBOLS = {
     "dvbs2_demap_estimate_snr_device": (_i, [_vp, _vp, _i, _vp, _vp]),
     "dvbs2_demap_refine_snr": (_i, [_vp, _vp, _vp, _i, _vp]),
     "dvbs2_demap_refine_snr_device": (_i, [_vp, _vp, _vp, _i, _vp, _vp]),
+    "dvbs2_plpayload_create": (_i, [C.POINTER(_vp), _i, _i, _i, _i, _i]),
+    "dvbs2_plpayload_destroy": (None, [_vp]),
+    "dvbs2_plpayload_params": (_i, [_vp, _ip, _ip, _ip]),
+    "dvbs2_plpayload_process": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
+    "dvbs2_plpayload_process_device": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "dvbs2_pl_scrambling_rn": (_i, [_i, _vp, _i]),
     "dvbs2_chain_create": (_i, [C.POINTER(_vp), _i, _i, _i, _i, _i, _i, _i]),
     "dvbs2_chain_destroy": (None, [_vp]),
     "dvbs2_chain_params": (_i, [_vp, _ip, _ip]),

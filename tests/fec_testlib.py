@@ -16,7 +16,7 @@ ORACLE_DIR = os.path.join(ROOT, "oracle")
 
 def _build_oracle():
     so = os.path.join(ORACLE_DIR, "liboracle.so")
-    srcs = [os.path.join(ORACLE_DIR, f) for f in ("ldpc_oracle.c", "bch_oracle.c", "demap_oracle.c", "bb_oracle.c")]
+    srcs = [os.path.join(ORACLE_DIR, f) for f in ("ldpc_oracle.c", "bch_oracle.c", "demap_oracle.c", "bb_oracle.c", "pl_oracle.c")]
     if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["make", "-C", ORACLE_DIR, "liboracle.so"], stdout=subprocess.DEVNULL)
     return so
@@ -58,6 +58,8 @@ def oracle():
         o.oracle_demap_snr_refined.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
         o.oracle_demap_snr_refined.restype = C.c_float
         o.oracle_bb_sequence.argtypes = [C.c_void_p, C.c_int]
+        o.oracle_pl_rn.argtypes = [C.c_int, C.c_void_p, C.c_int]
+        o.oracle_pl_payload.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_void_p, C.c_void_p]
         o.oracle_bb_descramble.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
         _oracle = o
     return _oracle
@@ -266,4 +268,16 @@ def oracle_bb_descramble(msg):
     msg = np.ascontiguousarray(msg, np.uint8)
     out = np.empty_like(msg)
     oracle().oracle_bb_descramble(ptr(msg), ptr(out), msg.shape[1], msg.shape[0])
+    return out
+
+
+def oracle_pl_payload(payload, n_slots, has_pilots, gold, plheader_phase, fine_foffset, coarse, pilot_phase):
+    """payload: (n_frames, payload_len) complex64 -> (n_frames, 90 n_slots) complex64 (lib/plsync_cc_impl.cc:644-795)."""
+    payload = np.ascontiguousarray(payload, np.complex64)
+    nf = payload.shape[0]
+    out = np.empty((nf, n_slots * 90), np.complex64)
+    pp = np.ascontiguousarray(pilot_phase, np.float32)
+    for f in range(nf):
+        oracle().oracle_pl_payload(ptr(payload[f]), n_slots, int(has_pilots), gold, float(plheader_phase[f]), float(fine_foffset[f]),
+                                   int(coarse[f]), ptr(np.ascontiguousarray(pp[f])), ptr(out[f]))
     return out

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 import fec_testlib as T
-from dvbs2rx_amd import BchDecoder, Demapper, FecChain, LdpcDecoder, bb_descramble_sequence, capi, get_fec_info
+from dvbs2rx_amd import BchDecoder, Demapper, FecChain, LdpcDecoder, PlPayload, bb_descramble_sequence, capi, get_fec_info
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(T.ROOT, "tests", "golden")
@@ -186,6 +186,50 @@ def test_unsupported_constellation_rejected():
     h = C.c_void_p()
     assert capi.lib.dvbs2_demap_create(C.byref(h), 1, 3, 3, 4, 0) == capi.EINVAL  # MOD_16APSK
     assert b"Unsupported constellation" in capi.lib.dvbs2_last_error()
+
+
+# ------------------------------------------------------------------ PLFRAME payload step
+@pytest.mark.parametrize("n_slots,has_pilots,gold", [(360, True, 0), (360, False, 0), (240, True, 5), (90, True, 131071),
+                                                     (144, False, 7), (36, True, 0)])
+def test_plframe_payload_step(n_slots, has_pilots, gold):
+    """Descramble + pilot removal + per-segment de-rotation vs the restatement of plsync_cc_impl::handle_payload():
+    coarse-corrected frames (rotator restarted from the pilot phases), not coarse-corrected ones (PLHEADER phase only),
+    and the inverse property: scrambling + rotating known symbols and running the step gives them back."""
+    pp = PlPayload(gold_code=gold, n_slots=n_slots, has_pilots=has_pilots, max_frames=4)
+    npil = ((n_slots - 1) >> 4) if has_pilots else 0
+    assert (pp.payload_len, pp.xfecframe_len, pp.n_pilots) == (90 * n_slots + 36 * npil, 90 * n_slots, npil)
+    rng = np.random.default_rng(n_slots + gold)
+    nf = 4
+    payload = (rng.normal(size=(nf, pp.payload_len)) + 1j * rng.normal(size=(nf, pp.payload_len))).astype(np.complex64) * 0.7
+    hph = rng.uniform(-np.pi, np.pi, nf).astype(np.float32)
+    fine = np.array([2.5e-4, -1.0e-4, 3.3e-4, 0.0], np.float32)
+    coarse = np.array([1, 1, 0, 1], np.int32)
+    pil = rng.uniform(-np.pi, np.pi, (nf, max(npil, 1))).astype(np.float32)
+    out = pp.work(payload, hph, fine, coarse, pil)
+    want = T.oracle_pl_payload(payload, n_slots, has_pilots, gold, hph, fine, coarse, pil)
+    assert np.abs(out - want).max() < 1e-4 * 4  # float rotator recurrence vs direct phase; |symbols| up to ~4
+    # inverse property on frame 0: x -> scramble(x) * exp(+j phase) -> step -> x
+    from dvbs2rx_amd import pl_scrambling_rn
+    rn = pl_scrambling_rn(gold, pp.payload_len)
+    x = (rng.normal(size=pp.xfecframe_len) + 1j * rng.normal(size=pp.xfecframe_len)).astype(np.complex64)
+    tx = np.zeros(pp.payload_len, np.complex128)
+    o = np.arange(pp.xfecframe_len)
+    blk = (o // 90 // 16) if has_pilots else np.zeros_like(o)
+    k = o + 36 * blk
+    inc = 2 * np.pi * float(fine[0])
+    theta0 = np.where(blk > 0, pil[0][np.maximum(blk - 1, 0)], hph[0]).astype(np.float64)
+    steps = np.where(blk > 0, o - blk * 1440, o)
+    tx[k] = x * np.exp(1j * (np.pi / 2) * rn[k]) * np.exp(1j * (theta0 + inc * steps))
+    back = pp.work(np.broadcast_to(tx.astype(np.complex64), (1, pp.payload_len)), hph[:1], fine[:1], coarse[:1], pil[:1])
+    assert np.abs(back[0] - x).max() < 2e-5 * 8
+    pp.close()
+
+
+def test_plframe_payload_rejects_bad_arguments():
+    import ctypes as C
+    h = C.c_void_p()
+    assert capi.lib.dvbs2_plpayload_create(C.byref(h), 0, 400, 1, 4, 0) == capi.EINVAL   # more than MAX_SLOTS
+    assert capi.lib.dvbs2_plpayload_create(C.byref(h), 1 << 18, 360, 1, 4, 0) == capi.EINVAL
 
 
 # ------------------------------------------------------------------ chain (BASELINE config 3 shape, small batch)

@@ -151,6 +151,20 @@ def test_bb_descrambler_sequence_known_answer():
     assert np.array_equal(T.oracle_bb_descramble(x)[1], x[1] ^ seq[:4026])
 
 
+@pytest.mark.parametrize("gold", [0, 1, 131071, 262141])
+def test_pl_scrambling_sequence_definition_vs_register_masks(gold):
+    """Rn of ETSI EN 302 307-1 clause 5.5.4 two ways: the product evaluates the definition (x and y m-sequences,
+    z_n(i) = x(i + n) + y(i), Rn = 2 z_n(i + 131072) + z_n(i)), the oracle follows the reference's shift registers with
+    the 0x8050 / 0xFF60 masks (lib/pl_descrambler.cc:62-98). Whole maximum payload."""
+    from dvbs2rx_amd import pl_scrambling_rn
+    n = 360 * 90 + 22 * 36
+    rn = np.zeros(n, np.uint8)
+    T.oracle().oracle_pl_rn(gold, T.ptr(rn), n)
+    assert rn.max() == 3 and np.array_equal(pl_scrambling_rn(gold, n), rn)
+    if gold == 0:  # x(0) = 1, y(0) = 1 => z(0) = 0; the sequence is balanced
+        assert rn[0] & 1 == 0 and abs(np.bincount(rn, minlength=4) / n - 0.25).max() < 0.02
+
+
 def test_fec_params_match_reference():
     """gr-dvbs2rx_amd's parameter map vs the reference's get_fec_info() + table switch (tests/golden/fec_params.json)."""
     g = json.load(open(os.path.join(GOLD, "fec_params.json")))
