@@ -13,13 +13,17 @@
 
 void oracle_bb_sequence(uint8_t* seq, int n_bytes)
 {
-    memset(seq, 0, (size_t)n_bytes);
-    int sr = 0x4A80;
-    for (int i = 0; i < 8 * n_bytes; i++) {
-        int b = (sr ^ (sr >> 1)) & 1;
-        seq[i / 8] |= (uint8_t)(b << (7 - (i % 8)));
-        sr >>= 1;
-        if (b) sr |= 0x4000;
+    /* 15-bit register loaded with 100101010000000 (0x4A80 with the first stage in bit 0); output = feedback =
+     * stage 14 xor stage 15 = bits 1 and 0 here; packed MSB first (lib/bbdescrambler_bb_impl.cc:51-65) */
+    uint32_t reg = 0x4A80u;
+    for (int byte = 0; byte < n_bytes; byte++) {
+        uint32_t acc = 0;
+        for (int bit = 0; bit < 8; bit++) {
+            const uint32_t fb = (reg ^ (reg >> 1)) & 1u;
+            acc = (acc << 1) | fb;
+            reg = (reg >> 1) | (fb << 14);
+        }
+        seq[byte] = (uint8_t)acc;
     }
 }
 

@@ -16,19 +16,21 @@
 #include <math.h>
 #include <stdint.h>
 
-static int par18(long a, long b) { a &= b; int c = 0; for (int i = 0; i < 18; i++) c += (a >> i) & 1; return c & 1; }
+/* 18-bit Fibonacci registers, bit 0 = oldest element of the m-sequence; parity of the masked register = an XOR of
+ * future sequence elements (the shift-and-add property the reference exploits, lib/pl_descrambler.cc:23-34). */
+static uint32_t tap(uint32_t reg, uint32_t mask) { return (uint32_t)__builtin_parity(reg & mask & 0x3FFFFu); }
+static uint32_t advance(uint32_t reg, uint32_t feedback_mask) { return (reg >> 1) | (tap(reg, feedback_mask) << 17); }
 
-/* Rn[i] in 0..3 for i < n (lib/pl_descrambler.cc:62-98) */
+/* Rn[i] in 0..3 for i < n. Feedback x: x^18 + x^7 + 1 (mask 0x81); y: y^18 + y^10 + y^7 + y^5 + 1 (mask 0x4A1);
+ * the element 131072 positions ahead is tap 0x8050 of x and tap 0xFF60 of y (lib/pl_descrambler.cc:62-98). */
 void oracle_pl_rn(int gold_code, uint8_t* rn, int n)
 {
-    long x = 0x00001, y = 0x3FFFF;
-    for (int k = 0; k < gold_code; k++) { int xb = par18(x, 0x0081); x >>= 1; if (xb) x |= 0x20000; }
-    for (int i = 0; i < n; i++) {
-        int xa = par18(x, 0x8050), xb = par18(x, 0x0081), xc = (int)(x & 1);
-        x >>= 1; if (xb) x |= 0x20000;
-        int ya = par18(y, 0x04A1), yb = par18(y, 0xFF60), yc = (int)(y & 1);
-        y >>= 1; if (ya) y |= 0x20000;
-        rn[i] = (uint8_t)(((xa ^ yb) << 1) + (xc ^ yc));
+    uint32_t xr = 1u, yr = 0x3FFFFu;
+    while (gold_code-- > 0) xr = advance(xr, 0x0081u);
+    for (int i = 0; i < n; i++, xr = advance(xr, 0x0081u), yr = advance(yr, 0x04A1u)) {
+        const uint32_t z_now = (xr ^ yr) & 1u;
+        const uint32_t z_far = tap(xr, 0x8050u) ^ tap(yr, 0xFF60u);
+        rn[i] = (uint8_t)(2u * z_far + z_now);
     }
 }
 
