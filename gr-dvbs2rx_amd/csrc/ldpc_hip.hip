@@ -106,9 +106,9 @@ LdpcDecoderHip::LdpcDecoderHip(const LdpcTableDesc* table, int out_bits_message,
     // "parity in records" variant (ldpc_kernel_pr.hpp): check degree <= 7, at most 4 hazard entries per layer, and two
     // pair workgroups must fit the 160 KB of LDS
     // Policy (measured on MI355X, tools/pr_sweep.sh; the two variants give identical bits): every eligible short and
-    // medium table gains 12-36 %, normal frames gain where every check has degree 7 (table B4: +10 %) and lose on the
-    // lowest rates with 100+ thin layers (B1, B3, S2X B1-B3: -5..-20 %). DVBS2_PR=0 / 1 overrides.
-    pr_ = dmax_ == 8 && degmax <= 7 && (sched_.N < 64800 || degmin >= 7);
+    // medium table gains 12-36 %, normal frames gain where every check has degree 7 and some layers are hazard layers whose latency the second
+    // workgroup hides (table B4: +3 %) and lose elsewhere (B1, B3, S2X B1-B3: -5..-20 %). DVBS2_PR=0 / 1 overrides.
+    pr_ = dmax_ == 8 && degmax <= 7 && (sched_.N < 64800 || (degmin >= 7 && sched_.conflict_layers > 0));
     if (const char* e = getenv("DVBS2_PR")) pr_ = dmax_ == 8 && degmax <= 7 && atoi(e) != 0;
     for (const LdpcLayer& L : sched_.layers)
         if (L.block < 360 && (L.n_conflict > 4 || (L.n_conflict > 2 ? 4 : 2) > L.cnt)) pr_ = false;
