@@ -89,6 +89,9 @@ LdpcDecoderHip::LdpcDecoderHip(const LdpcTableDesc* table, int out_bits_message,
     HIP_OK(hipSetDevice(device_));
     const int RS = rec_stride(dmax_);
     std::vector<uint32_t> hr((size_t)sched_.q * RS, 0);
+    int lane_chain_max = 64;
+    if (const char* e = getenv("DVBS2_LANE_CHAIN_MAX")) lane_chain_max = std::min(64, atoi(e)); // experiments
+    if ((sched_.N / 360) * kSvWords < kLaneChainWords) lane_chain_max = 0;
     for (int i = 0; i < sched_.q; i++) {
         const LdpcLayer& L = sched_.layers[i];
         uint32_t nc_code = 0;
@@ -96,9 +99,24 @@ LdpcDecoderHip::LdpcDecoderHip(const LdpcTableDesc* table, int out_bits_message,
             nc_code = L.n_conflict <= 2 ? 2 : L.n_conflict <= 4 ? 4 : 8;
             if (L.n_conflict > kMaxHazard || (int)nc_code > L.cnt) nc_code = kHazardWalk;
         }
-        hr[(size_t)i * RS] = L.cnt | (nc_code << 8) | ((uint32_t)L.sync_before << 15) | ((uint32_t)L.block << 16);
+        // A layer whose only hazard is ONE pair (two entries of one group) with a small block is walked as a lane
+        // chain (check_node_hazard): the pair is ordered so that entry 0's bit of row j is entry 1's bit of row
+        // j + block, i.e. (rot0 - rot1) mod 360 == block; header bit 12. Needs kLaneChainWords of scratch per frame in
+        // the sign-vector area (the shared area of the parity-in-records layout is checked below).
+        int order[64];
+        for (int k = 0; k < L.cnt + 2; k++) order[k] = k;
+        uint32_t chain = 0;
+        if (L.block <= lane_chain_max && nc_code == 2 && L.n_conflict == 2 && L.cnt + 2 <= kLaneChainMaxDeg) {
+            const LdpcEntry& a = sched_.entries[L.entry_off], & b = sched_.entries[L.entry_off + 1];
+            if (a.base == b.base) {
+                const int D = ((int)a.rot - (int)b.rot + 360) % 360;
+                if (D == L.block) chain = 1;
+                else if (360 - D == L.block) { order[0] = 1; order[1] = 0; chain = 1; }
+            }
+        }
+        hr[(size_t)i * RS] = L.cnt | (nc_code << 8) | (chain << 12) | ((uint32_t)L.sync_before << 15) | ((uint32_t)L.block << 16);
         for (int k = 0; k < L.cnt + 2; k++) {
-            const LdpcEntry& e = sched_.entries[L.entry_off + k];
+            const LdpcEntry& e = sched_.entries[L.entry_off + order[k]];
             hr[(size_t)i * RS + 4 + 2 * k] = (uint32_t)e.base + e.rot;
             hr[(size_t)i * RS + 5 + 2 * k] = 360u - e.rot;
         }
@@ -106,13 +124,15 @@ LdpcDecoderHip::LdpcDecoderHip(const LdpcTableDesc* table, int out_bits_message,
     // "parity in records" variant (ldpc_kernel_pr.hpp): check degree <= 7, at most 4 hazard entries per layer, and two
     // pair workgroups must fit the 160 KB of LDS
     // Policy (measured on MI355X, tools/pr_sweep.sh; the two variants give identical bits): every eligible short and
-    // medium table gains 12-36 %, normal frames gain where every check has degree 7 and some layers are hazard layers whose latency the second
-    // workgroup hides (table B4: +3 %) and lose elsewhere (B1, B3, S2X B1-B3: -5..-20 %). DVBS2_PR=0 / 1 overrides.
-    pr_ = dmax_ == 8 && degmax <= 7 && (sched_.N < 64800 || (degmin >= 7 && sched_.conflict_layers > 0));
+    // medium table gains 12-43 % from the second workgroup per CU. On normal frames the classic kernel is as fast or
+    // faster since its hazard layers run as lane chains (B4: 109 k vs 106 k frames/s; thin-layer tables lose up to
+    // 20 % with parity-in-records). DVBS2_PR=0 / 1 overrides.
+    pr_ = dmax_ == 8 && degmax <= 7 && sched_.N < 64800;
     if (const char* e = getenv("DVBS2_PR")) pr_ = dmax_ == 8 && degmax <= 7 && atoi(e) != 0;
     for (const LdpcLayer& L : sched_.layers)
         if (L.block < 360 && (L.n_conflict > 4 || (L.n_conflict > 2 ? 4 : 2) > L.cnt)) pr_ = false;
     if (2 * pr_lds_bytes(sched_.N, sched_.K) > 160 * 1024) pr_ = false;
+    if (pr_) for (int i = 0; i < sched_.q; i++) hr[(size_t)i * RS] &= ~(1u << 12); // that kernel has no lane chain (80 VGPRs)
     if (pr_) {
         const int q = sched_.q;
         hr[(size_t)(q - 1) * RS + 4 + 2 * sched_.layers[q - 1].cnt] = (uint32_t)sched_.K;          // own parity of the last layer: row q-1 at offset K

@@ -200,11 +200,16 @@ __device__ __forceinline__ void check_node(uint8_t* __restrict__ lds /*the whole
 // a regular entry's bits are touched by exactly one row of the layer.
 // NC (2, 4 or 8) is the number of entries handled in P2: the hazard entries, rounded up with regular data entries
 // (moving a regular entry into the ordered part does not change the result).
+constexpr int kLaneChainRows = 424;                                   // 360 rows + one block of padding
+constexpr int kLaneChainWords = kLaneChainRows + kLaneChainRows / 4;  // per-row record (dword) + per-row log (byte)
+constexpr int kLaneChainMaxDeg = 16;                                  // not instantiated for the big variants nor for the
+                                                                      // 80-VGPR parity-in-records kernel (registers)
 constexpr int kMaxHazard = 8;
 constexpr int kHazardWalk = 15; // header code: too many hazard entries, fall back to the single-wave chunk walk
 template <int DEG, int NC, bool LAYER0, bool PR = false, bool LAST = false>
 __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, const uint32_t* ent, int jj, int lb, bool work,
-                                                  int block, const uint32_t* mw, uint32_t* nm, int own_in = 0, int* carry = nullptr)
+                                                  int block, const uint32_t* mw, uint32_t* nm, int own_in = 0, int* carry = nullptr,
+                                                  uint32_t* tab = nullptr /*kLaneChainWords of LDS scratch when the layer is a lane chain*/)
 {
     constexpr bool OWN_REG = PR && !LAST;     // entry DEG-2 (see check_node)
     constexpr bool PREV_REG = PR && !LAYER0;  // entry DEG-1
@@ -249,8 +254,84 @@ __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, con
     // next block reads what this one wrote), so its length is what a hazard layer costs: rel = jj - start is kept
     // incrementally (one subtract + one unsigned compare select the rows of the block).
     __builtin_amdgcn_s_setprio(3);
-    int rel = work ? jj : 0x40000000;
-    for (int start = 0; start < kM; start += block, rel -= block) {
+    bool lane_chain = false;
+    if constexpr (NC == 2 && DEG <= kLaneChainMaxDeg && !PR) lane_chain = tab != nullptr; // wave-uniform (header bit 12)
+    if constexpr (NC == 2 && DEG <= kLaneChainMaxDeg && !PR) if (lane_chain) {
+        // LANE CHAIN (one hazard pair, block <= 64, host-ordered so that entry 0's bit of row r is entry 1's bit of
+        // row r + block). A lone wave issues one instruction per ~6.7 cycles whatever it is, so an ordered step costs
+        // its instruction count: the recurrence r -> r + block is walked by the `block` lanes that own rows
+        // 0..block-1 with the chained LLR in a register, ~20 instructions per step, no exec-mask bookkeeping, no LDS
+        // hand-over, no barrier per step; everything else happens before and after, in parallel over all rows:
+        //   A  rows < block (chain heads, nothing precedes them): full two-entry step; entry-1 LLR written at once
+        //      (rows >= 360 - block read it as their entry-0 LLR)                                        | barrier
+        //   B  rows >= block: read entry 0 (no earlier row of this layer writes it), publish
+        //      {inp0, partial min0, partial sign, message byte 1}                                        | barrier
+        //   C  chain lanes: incoming entry-1 LLR -> new entry-0 LLR of row r, incoming value logged      | barrier
+        //   D  rows >= block: complete both outputs from the logged value; write entry 1; the last row of a chain
+        //      also writes entry 0 (in the reference's order it is the final writer of that bit).
+        uint8_t* ulog = reinterpret_cast<uint8_t*>(tab + kLaneChainRows);
+        int chained = 0x80;
+        const bool head = work && jj < block, body = work && jj >= block;
+        if (head) {
+            const int L0 = lds[ad[0]], L1 = lds[ad[1]];
+            inp[0] = min(max(L0 - hmb[0], -128), 127);
+            inp[1] = min(max(L1 - hmb[1], -128), 127);
+            mg[0] = mag_raw(L0, hmb[0]);
+            mg[1] = mag_raw(L1, hmb[1]);
+            int o0, o1;
+            asm("v_med3_i32 %0, %1, 0, %2" : "=v"(o0) : "v"(mg[1]), "v"(min0));
+            asm("v_med3_i32 %0, %1, 0, %2" : "=v"(o1) : "v"(mg[0]), "v"(min0));
+            const int s0 = (signs ^ inp[1]) >> 31, s1 = (signs ^ inp[0]) >> 31;
+            hout[0] = (o0 ^ s0) - s0;
+            hout[1] = (o1 ^ s1) - s1;
+            chained = sat_sum_u8(inp[0], hout[0]);
+            lds[ad[1]] = (uint8_t)sat_sum_u8(inp[1], hout[1]);
+        }
+        __syncthreads();
+        if (body) {
+            const int L0 = lds[ad[0]];
+            inp[0] = min(max(L0 - hmb[0], -128), 127);
+            mg[0] = mag_raw(L0, hmb[0]);
+            tab[jj] = ((uint32_t)inp[0] & 0x1ffu) | ((uint32_t)min0 << 9) | (((uint32_t)signs >> 31) << 16) | ((uint32_t)hmb[1] << 24);
+        }
+        __syncthreads();
+        if (head) {
+            // rows past 359 read the padding of the table and log into the padding: no per-lane predicate in the loop
+            const uint32_t* tp = tab + jj + block;
+            uint8_t* up = ulog + jj + block;
+            uint32_t t = *tp;
+            for (int first = block; first < kM; first += block) {
+                const uint32_t tc = t;
+                tp += block;
+                t = *tp; // next row's record, in flight during this step
+                const int i0 = (int)(tc << 23) >> 23, P = (int)((tc >> 9) & 0x7fu), m1 = (int)(tc >> 24);
+                const int sw = (int)(tc << 15); // partial sign in bit 31
+                *up = (uint8_t)chained; up += block;
+                const int i1 = min(max(chained - m1, -128), 127);
+                const int g1 = mag_raw(chained, m1);
+                int o0;
+                asm("v_med3_i32 %0, %1, 0, %2" : "=v"(o0) : "v"(g1), "v"(P));
+                const int s0 = (sw ^ i1) >> 31;
+                chained = sat_sum_u8(i0, (o0 ^ s0) - s0);
+            }
+        }
+        __syncthreads();
+        if (body) {
+            const int L1 = ulog[jj];
+            inp[1] = min(max(L1 - hmb[1], -128), 127);
+            mg[1] = mag_raw(L1, hmb[1]);
+            int o0, o1;
+            asm("v_med3_i32 %0, %1, 0, %2" : "=v"(o0) : "v"(mg[1]), "v"(min0));
+            asm("v_med3_i32 %0, %1, 0, %2" : "=v"(o1) : "v"(mg[0]), "v"(min0));
+            const int s0 = (signs ^ inp[1]) >> 31, s1 = (signs ^ inp[0]) >> 31;
+            hout[0] = (o0 ^ s0) - s0;
+            hout[1] = (o1 ^ s1) - s1;
+            lds[ad[1]] = (uint8_t)sat_sum_u8(inp[1], hout[1]);
+            if (jj + block >= kM) lds[ad[0]] = (uint8_t)sat_sum_u8(inp[0], hout[0]);
+        }
+    }
+    int rel = (work && !lane_chain) ? jj : 0x40000000;
+    for (int start = lane_chain ? kM : 0; start < kM; start += block, rel -= block) {
         if ((uint32_t)rel < (uint32_t)block) {
             if constexpr (NC == 2) {
                 // two hazard entries: each one's magnitude sent back is min(partial min0, the other's magnitude) =
@@ -339,7 +420,7 @@ __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, con
         default: break; }
 
 #define DVBS2_HAZ_CALL(D, NCV) { if constexpr (D - 2 >= NCV) { \
-        if (layer0) check_node_hazard<D, NCV, true>(lds_all, ent, jj, lb, work, block, mw, nm); else check_node_hazard<D, NCV, false>(lds_all, ent, jj, lb, work, block, mw, nm); } }
+        if (layer0) check_node_hazard<D, NCV, true>(lds_all, ent, jj, lb, work, block, mw, nm, 0, nullptr, htab); else check_node_hazard<D, NCV, false>(lds_all, ent, jj, lb, work, block, mw, nm, 0, nullptr, htab); } }
 #define DVBS2_HAZ_CASE(D) case D: if constexpr (D >= 4 && D <= DMAX && D > DMAX - 8) { \
         if (nc == 2) DVBS2_HAZ_CALL((D >= 4 ? D : 4), 2) else if (nc == 4) DVBS2_HAZ_CALL((D >= 4 ? D : 4), 4) else DVBS2_HAZ_CALL((D >= 4 ? D : 4), 8) } break;
 #define DVBS2_HAZ_SWITCH switch (deg) { \
@@ -540,6 +621,7 @@ __global__ __launch_bounds__(kThreads) void ldpc_layered_kernel(
             }
             const int deg = (int)(hdr & 0xffu) + 2;
             const int nc = (int)((hdr >> 8) & 0xfu);
+            uint32_t* htab = ((hdr >> 12) & 1u) ? sv : nullptr; // lane-chain scratch: the sign-vector area is idle during a sweep
             const int block = (int)(hdr >> 16);
             const bool layer0 = (i == 0);
             uint32_t* mp = msg_base + (size_t)i * MW * kMsgStride;

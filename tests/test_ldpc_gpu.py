@@ -196,8 +196,8 @@ def test_parity_in_records_variant(monkeypatch, force):
 
 
 def test_kernel_variant_policy(monkeypatch):
-    """Which sweep kernel a handle launches (dvbs2_ldpc_kernel_name): parity-in-records for short/medium frames and
-    for normal frames whose checks all have degree 7; the classic variant of the table's degree class otherwise."""
+    """Which sweep kernel a handle launches (dvbs2_ldpc_kernel_name): parity-in-records for short/medium frames with
+    check degree <= 7; the classic variant of the table's degree class otherwise."""
     def name(table, **env):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -208,12 +208,14 @@ def test_kernel_variant_policy(monkeypatch):
         for k in env:
             monkeypatch.delenv(k)
         return n
-    assert name("S2_TABLE_B4") == "ldpc_layered_pr_kernel"
+    assert name("S2_TABLE_B4") == "ldpc_layered_kernel<8>"       # normal frames: classic kernel (hazard layers as lane chains)
     assert name("S2_TABLE_C1") == "ldpc_layered_pr_kernel"
+    assert name("S2X_TABLE_C9") == "ldpc_layered_pr_kernel"       # medium frame
     assert name("S2_TABLE_B1") == "ldpc_layered_kernel<8>"       # 135 thin layers: the classic kernel is faster
     assert name("S2_TABLE_B7") == "ldpc_layered_kernel<16>"
     assert name("S2_TABLE_B11") == "ldpc_layered_kernel<32>"
-    assert name("S2_TABLE_B4", DVBS2_PR="0") == "ldpc_layered_kernel<8>"
+    assert name("S2_TABLE_C1", DVBS2_PR="0") == "ldpc_layered_kernel<8>"
+    assert name("S2_TABLE_B4", DVBS2_PR="1") == "ldpc_layered_pr_kernel"
     assert name("S2_TABLE_B1", DVBS2_PR="1") == "ldpc_layered_pr_kernel"
 
 
