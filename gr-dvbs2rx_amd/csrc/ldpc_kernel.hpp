@@ -202,7 +202,7 @@ __device__ __forceinline__ void check_node(uint8_t* __restrict__ lds /*the whole
 // (moving a regular entry into the ordered part does not change the result).
 constexpr int kLaneChainRows = 424;                                   // 360 rows + one block of padding
 constexpr int kLaneChainWords = kLaneChainRows + kLaneChainRows / 4;  // per-row record (dword) + per-row log (byte)
-constexpr int kLaneChainMaxDeg = 16;                                  // not instantiated for the big variants nor for the
+constexpr int kLaneChainMaxDeg = 28;                                  // not instantiated for the big variants nor for the
                                                                       // 80-VGPR parity-in-records kernel (registers)
 constexpr int kMaxHazard = 8;
 constexpr int kHazardWalk = 15; // header code: too many hazard entries, fall back to the single-wave chunk walk
