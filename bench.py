@@ -105,12 +105,20 @@ def bench_chain(args, world, rank, local, dev):
     dt = shard.max_over_ranks(time.perf_counter() - t0, device=dev)
     if rank == 0:
         fps = world * nf * args.steps / dt
+        b_alg = 237600 + (64800 + 48600 // 8 + args.trials * 2 * 226799) + 12126
         print(json.dumps({"metric": "FECFRAMEs/sec, 8PSK 3/4 normal demap+LDPC+BCH chain", "value": fps, "unit": "frames/s",
                           "coded_gbps": fps * 64800 / 1e9, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
                           "vs_baseline": None, "dtype": "int8", "data": "synthetic",
                           "config": {"workload": f"8PSK 3/4 normal (DVB_S2_TABLE_B7 + BCH(48600,48408,t=12)), {args.trials} LDPC "
-                                                 f"iterations cap, batch={nf} per GPU, noise-only symbols", "frames_per_gpu": nf}}))
+                                                 f"iterations cap, batch={nf} per GPU, noise-only symbols", "frames_per_gpu": nf},
+                          # demap 237 600 + LDPC (N + K/8 + I*2*LT) + BCH 12 126 bytes per frame, against
+                          # the time of the whole step (three kernels, the LDPC sweep dominates)
+                          "roofline": {"bound": "hbm", "achieved": b_alg * nf * world * args.steps / dt / world / 1e9,
+                                       "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                       "frac": b_alg * nf * args.steps / dt / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                                       "kernel": "whole chain step: demap_8psk_kernel + ldpc_layered_kernel<16> + bch_decode_kernel",
+                                       "algorithmic_bytes_per_frame": b_alg}}))
     shard.finalize()
 
 
