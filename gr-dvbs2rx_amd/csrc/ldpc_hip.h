@@ -50,6 +50,7 @@ private:
     uint32_t* d_recs_ = nullptr;  // per-layer records (ldpc_hip.hip)
     size_t lds_bytes_ = 0;
     std::string kname_;
+    bool dense_ = false;          // 80-VGPR build of the classic kernel selected (two workgroups per CU)
     bool pr_ = false;             // parity-in-records kernel variant selected (ldpc_kernel_pr.hpp)
     unsigned long long* d_tdbg_ = nullptr; // DVBS2_TIMING=1: per-wave cycle-counter breakdown (diagnostics)
     uint8_t* d_state_ = nullptr;  // max_frames * N, internal layout, offset-binary LLRs

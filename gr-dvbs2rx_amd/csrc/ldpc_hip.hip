@@ -152,7 +152,13 @@ LdpcDecoderHip::LdpcDecoderHip(const LdpcTableDesc* table, int out_bits_message,
     HIP_OK(hipEventCreate(&ev0_));
     HIP_OK(hipEventCreate(&ev1_));
     if (getenv("DVBS2_TIMING")) { HIP_OK(hipMalloc(&d_tdbg_, (size_t)max_frames_ * 6 * 8 * 8)); HIP_OK(hipMemset(d_tdbg_, 0, (size_t)max_frames_ * 6 * 8 * 8)); }
-    kname_ = pr_ ? std::string("ldpc_layered_pr_kernel") : "ldpc_layered_kernel<" + std::to_string(dmax_) + ">";
+    // Short frames whose layers are mostly hazard layers (latency-bound ordered steps) and whose degree rules out the
+    // parity-in-records kernel: the 80-VGPR build puts a second workgroup on the CU (measured: short 3/5 and 2/3 +34 %;
+    // it costs 6-18 % where regular layers dominate, hence the 70 % threshold; degree classes above 12 do not fit 80 VGPRs). DVBS2_DENSE=0 / 1 overrides.
+    dense_ = !pr_ && sched_.N < 64800 && dmax_ == 12 && 10 * sched_.conflict_layers >= 7 * sched_.q &&
+             4 * half_lds_bytes(sched_.N) <= 160 * 1024;
+    if (const char* e = getenv("DVBS2_DENSE")) dense_ = !pr_ && dmax_ == 12 && atoi(e) != 0 && 4 * half_lds_bytes(sched_.N) <= 160 * 1024;
+    kname_ = pr_ ? std::string("ldpc_layered_pr_kernel") : "ldpc_layered_kernel<" + std::to_string(dmax_) + (dense_ ? ", dense>" : ">");
     lds_bytes_ = pr_ ? pr_lds_bytes(sched_.N, sched_.K) : 2 * half_lds_bytes(sched_.N);
     if (const char* e = getenv("DVBS2_LDS_PAD")) lds_bytes_ += (size_t)atoi(e); // occupancy experiments only
     if (pr_) HIP_OK(ldpc_pr_prepare(lds_bytes_));
@@ -188,7 +194,7 @@ int LdpcDecoderHip::decode_device(const int8_t* d_llr_in, int n_frames, int max_
         LdpcLaunch la;
         la.recs = d_recs_; la.llr_in = in; la.state = d_state_; la.msgs = d_msgs_; la.iters = d_iters_; la.good = d_good_; la.target = target;
         la.n_frames = n_frames; la.N = sched_.N; la.K = sched_.K; la.q = sched_.q; la.cap = max_trials; la.stop_on_good = stop_on_good;
-        la.tdbg = d_tdbg_; la.lds_bytes = lds_bytes; la.stream = stream;
+        la.tdbg = d_tdbg_; la.lds_bytes = lds_bytes; la.stream = stream; la.dense = dense_;
         if (pr_) ldpc_pr_launch(la);
         else switch (dmax_) {
             case 8: ldpc_variant_launch<8>(la); break;   case 12: ldpc_variant_launch<12>(la); break;

@@ -431,8 +431,10 @@ __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, con
         DVBS2_HAZ_CASE(27) DVBS2_HAZ_CASE(28) DVBS2_HAZ_CASE(29) DVBS2_HAZ_CASE(30) DVBS2_HAZ_CASE(31) DVBS2_HAZ_CASE(32) \
         default: break; }
 
-template <int DMAX, bool TIMING>
-__global__ __launch_bounds__(kThreads) void ldpc_layered_kernel(
+// MINW = 6 ("dense"): compiled for 80 VGPRs so that two pair-workgroups share a CU when the frames are short enough for
+// LDS. It spills and only pays where ordered hazard steps dominate (ldpc_hip.hip picks it).
+template <int DMAX, bool TIMING, int MINW = 1>
+__global__ __launch_bounds__(kThreads, MINW) void ldpc_layered_kernel(
     const uint32_t* __restrict__ recs, const int8_t* __restrict__ llr_in, uint8_t* __restrict__ state,
     uint32_t* __restrict__ msgs, int* __restrict__ iters, int* __restrict__ good, const int* __restrict__ target,
     int n_frames, int N, int K, int q, int cap, int stop_on_good, unsigned long long* __restrict__ tdbg)
@@ -709,6 +711,7 @@ struct LdpcLaunch {
     const uint32_t* recs; const int8_t* llr_in; uint8_t* state; uint32_t* msgs; int* iters; int* good; const int* target;
     int n_frames, N, K, q, cap, stop_on_good; unsigned long long* tdbg;
     size_t lds_bytes; hipStream_t stream;
+    bool dense; // the 80-VGPR build of the kernel (two workgroups per CU), see kDenseBuilt
 };
 template <int DMAX> hipError_t ldpc_variant_prepare(size_t lds_bytes);
 template <int DMAX> void ldpc_variant_launch(const LdpcLaunch& a);
@@ -717,10 +720,17 @@ template <int DMAX> void ldpc_variant_launch(const LdpcLaunch& a);
 // The cycle-stamped variant (DVBS2_TIMING=1, tools/exp_tables.py) is only built for DMAX = 8 -- the headline tables --
 // to keep the build time of the large variants down; elsewhere the request is ignored.
 template <int DMAX> constexpr bool kTimingBuilt = (DMAX == 8);
+// only the degree class 5..12 survives 80 VGPRs (120 B of scratch); the classes of short 5/6 and 8/9 (DMAX 20, 28) spill so
+// much that they run 8x slower (measured)
+template <int DMAX> constexpr bool kDenseBuilt = (DMAX == 12);
 template <int DMAX> hipError_t ldpc_variant_prepare(size_t lds_bytes)
 {
     hipError_t e = hipFuncSetAttribute((const void*)ldpc_layered_kernel<DMAX, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return e;
+    if constexpr (kDenseBuilt<DMAX>) {
+        e = hipFuncSetAttribute((const void*)ldpc_layered_kernel<DMAX, false, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return e;
+    }
     if constexpr (kTimingBuilt<DMAX>)
         return hipFuncSetAttribute((const void*)ldpc_layered_kernel<DMAX, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     return hipSuccess;
@@ -732,6 +742,13 @@ template <int DMAX> void ldpc_variant_launch(const LdpcLaunch& a)
         if (a.tdbg) {
             hipLaunchKernelGGL((ldpc_layered_kernel<DMAX, true>), grid, block, a.lds_bytes, a.stream, a.recs, a.llr_in, a.state, a.msgs,
                                a.iters, a.good, a.target, a.n_frames, a.N, a.K, a.q, a.cap, a.stop_on_good, a.tdbg);
+            return;
+        }
+    }
+    if constexpr (kDenseBuilt<DMAX>) {
+        if (a.dense) {
+            hipLaunchKernelGGL((ldpc_layered_kernel<DMAX, false, 6>), grid, block, a.lds_bytes, a.stream, a.recs, a.llr_in, a.state, a.msgs,
+                               a.iters, a.good, a.target, a.n_frames, a.N, a.K, a.q, a.cap, a.stop_on_good, nullptr);
             return;
         }
     }

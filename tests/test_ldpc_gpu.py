@@ -67,6 +67,7 @@ def test_every_table_bit_exact(table, variant, monkeypatch):
     variant the library picks for the table and with the classic kernel forced."""
     if variant == "classic":
         monkeypatch.setenv("DVBS2_PR", "0")
+        monkeypatch.setenv("DVBS2_DENSE", "0")
     N = T.ldpc_info(table)[0]
     assert compare(table, T.llr_noise(32, N, 777), 32, 3).tolist() == [-1]
     llr, _ = T.llr_codeword_awgn(table, 32, 4242, amp=12, sigma=3.0)
@@ -214,6 +215,9 @@ def test_kernel_variant_policy(monkeypatch):
     assert name("S2_TABLE_B1") == "ldpc_layered_kernel<8>"       # 135 thin layers: the classic kernel is faster
     assert name("S2_TABLE_B7") == "ldpc_layered_kernel<16>"
     assert name("S2_TABLE_B11") == "ldpc_layered_kernel<32>"
+    assert name("S2_TABLE_C5") == "ldpc_layered_kernel<12, dense>"  # short 3/5: 16 of 18 layers are hazard layers
+    assert name("S2_TABLE_C5", DVBS2_DENSE="0") == "ldpc_layered_kernel<12>"
+    assert name("S2X_TABLE_C5") == "ldpc_layered_kernel<12>"      # same degree class, no hazard layers
     assert name("S2_TABLE_C1", DVBS2_PR="0") == "ldpc_layered_kernel<8>"
     assert name("S2_TABLE_B4", DVBS2_PR="1") == "ldpc_layered_pr_kernel"
     assert name("S2_TABLE_B1", DVBS2_PR="1") == "ldpc_layered_pr_kernel"
