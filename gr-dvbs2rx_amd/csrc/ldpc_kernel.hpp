@@ -33,9 +33,8 @@ __device__ __forceinline__ int wrap360(int t) { return t >= kM ? t - kM : t; }
 // clamp(a + b + 128, 0, 255) as v_add3_u32 + v_med3_i32 (the compiler emits add, max, add, min).
 __device__ __forceinline__ int sat_sum_u8(int a, int b)
 {
-    int t, r;
-    asm("v_add3_u32 %0, %1, %2, %3" : "=v"(t) : "v"(a), "v"(b), "s"(128));
-    asm("v_med3_i32 %0, %1, 0, %2" : "=v"(r) : "v"(t), "s"(255));
+    int r; // one asm statement: between two the compiler puts an s_nop (it cannot see that the pair has no hazard)
+    asm("v_add3_u32 %0, %1, %2, %3\n\tv_med3_i32 %0, %0, 0, %4" : "=&v"(r) : "v"(a), "v"(b), "s"(128), "s"(255));
     return r;
 }
 // R2: mag = clamp(|Lb - mb| - 1, 0, 126) as v_sad_u16 + v_med3_i32 (the compiler splits the clamp into max + min)
