@@ -45,6 +45,14 @@ __device__ __forceinline__ int mag_offset(int Lb, int mb)
     asm("v_med3_i32 %0, %1, 0, %2" : "=v"(r) : "v"(a), "s"(126));
     return r;
 }
+// LLR bytes are addressed with ABSOLUTE LDS addresses (the row index carries the frame's offset and the address of
+// the dynamic LDS array): going through the array symbol costs one `v_add_u32 v, <lds_all>, v` per access, because the
+// array's address is a link-time constant the compiler cannot fold into an address that inline asm produced.
+typedef __attribute__((address_space(3))) uint8_t lds_byte_t;
+__device__ __forceinline__ int lds_rd(int a) { return *reinterpret_cast<const lds_byte_t*>((size_t)(uint32_t)a); }
+__device__ __forceinline__ void lds_wr(int a, int v) { *reinterpret_cast<lds_byte_t*>((size_t)(uint32_t)a) = (uint8_t)v; }
+__device__ __forceinline__ int lds_address_of(const uint8_t* p) { return (int)(uint32_t)(size_t)(const lds_byte_t*)p; }
+
 // LDS address of check row jj for entry (S0 = 360*g + rot, thr = 360 - rot): S0 + jj, minus 360 when jj >= thr.
 // The canonical compare + select + add3 is three half-rate VALU instructions; this is four full-rate ones (2.5 vs 4.3
 // cycles each on gfx950): subtract, sign mask, bitfield select between jj and jj - 360 (v_bitop3), add.
@@ -137,7 +145,7 @@ __device__ __forceinline__ void check_node(uint8_t* __restrict__ lds /*the whole
     for (int k = 0; k < DEG; k++) {
         if (OWN_REG && k == DEG - 2) Lb[k] = own_in;
         else if (PREV_REG && k == DEG - 1) Lb[k] = *carry;
-        else Lb[k] = lds[ad[k]];
+        else Lb[k] = lds_rd(ad[k]);
     }
     // check (0,0) has no previous-parity link (layered_decoder.hh:56,63-66)
     const bool last_valid = !LAYER0 || jj != 0;
@@ -173,7 +181,7 @@ __device__ __forceinline__ void check_node(uint8_t* __restrict__ lds /*the whole
         const int nl = sat_sum_u8(inp[k], out);
         if (OWN_REG && k == DEG - 2) *carry = nl;
         else if (PREV_REG && k == DEG - 1) spare = nl;
-        else if (!(LAYER0 && k == DEG - 1) || last_valid) lds[ad[k]] = (uint8_t)nl;
+        else if (!(LAYER0 && k == DEG - 1) || last_valid) lds_wr(ad[k], nl);
         msgc[k] = min(max(out, -32), 31);
     }
     __builtin_amdgcn_s_setprio(3);
@@ -227,7 +235,7 @@ __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, con
 #pragma unroll
         for (int k = 0; k < DEG; k++) {
             if (k >= NC) { // regular entry
-                const int Lb = (OWN_REG && k == DEG - 2) ? own_in : (PREV_REG && k == DEG - 1) ? *carry : (int)lds[ad[k]];
+                const int Lb = (OWN_REG && k == DEG - 2) ? own_in : (PREV_REG && k == DEG - 1) ? *carry : lds_rd(ad[k]);
                 const int mb = (int)((mw[k >> 2] >> (8 * (k & 3))) & 0xffu);
                 int d = min(max(Lb - mb, -128), 127);
                 int mag = mag_raw(Lb, mb);
@@ -272,7 +280,7 @@ __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, con
         int chained = 0x80;
         const bool head = work && jj < block, body = work && jj >= block;
         if (head) {
-            const int L0 = lds[ad[0]], L1 = lds[ad[1]];
+            const int L0 = lds_rd(ad[0]), L1 = lds_rd(ad[1]);
             inp[0] = min(max(L0 - hmb[0], -128), 127);
             inp[1] = min(max(L1 - hmb[1], -128), 127);
             mg[0] = mag_raw(L0, hmb[0]);
@@ -284,11 +292,11 @@ __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, con
             hout[0] = (o0 ^ s0) - s0;
             hout[1] = (o1 ^ s1) - s1;
             chained = sat_sum_u8(inp[0], hout[0]);
-            lds[ad[1]] = (uint8_t)sat_sum_u8(inp[1], hout[1]);
+            lds_wr(ad[1], sat_sum_u8(inp[1], hout[1]));
         }
         __syncthreads();
         if (body) {
-            const int L0 = lds[ad[0]];
+            const int L0 = lds_rd(ad[0]);
             inp[0] = min(max(L0 - hmb[0], -128), 127);
             mg[0] = mag_raw(L0, hmb[0]);
             tab[jj] = ((uint32_t)inp[0] & 0x1ffu) | ((uint32_t)min0 << 9) | (((uint32_t)signs >> 31) << 16) | ((uint32_t)hmb[1] << 24);
@@ -325,8 +333,8 @@ __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, con
             const int s0 = (signs ^ inp[1]) >> 31, s1 = (signs ^ inp[0]) >> 31;
             hout[0] = (o0 ^ s0) - s0;
             hout[1] = (o1 ^ s1) - s1;
-            lds[ad[1]] = (uint8_t)sat_sum_u8(inp[1], hout[1]);
-            if (jj + block >= kM) lds[ad[0]] = (uint8_t)sat_sum_u8(inp[0], hout[0]);
+            lds_wr(ad[1], sat_sum_u8(inp[1], hout[1]));
+            if (jj + block >= kM) lds_wr(ad[0], sat_sum_u8(inp[0], hout[0]));
         }
     }
     int rel = (work && !lane_chain) ? jj : 0x40000000;
@@ -335,7 +343,7 @@ __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, con
             if constexpr (NC == 2) {
                 // two hazard entries: each one's magnitude sent back is min(partial min0, the other's magnitude) =
                 // med3(raw other, 0, min0) (min0 is already clamped to [0, 126])
-                const int L0 = lds[ad[0]], L1 = lds[ad[1]];
+                const int L0 = lds_rd(ad[0]), L1 = lds_rd(ad[1]);
                 inp[0] = min(max(L0 - hmb[0], -128), 127);
                 inp[1] = min(max(L1 - hmb[1], -128), 127);
                 mg[0] = mag_raw(L0, hmb[0]);
@@ -346,12 +354,12 @@ __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, con
                 const int s0 = (signs ^ inp[1]) >> 31, s1 = (signs ^ inp[0]) >> 31;
                 hout[0] = (o0 ^ s0) - s0;
                 hout[1] = (o1 ^ s1) - s1;
-                lds[ad[0]] = (uint8_t)sat_sum_u8(inp[0], hout[0]);
-                lds[ad[1]] = (uint8_t)sat_sum_u8(inp[1], hout[1]);
+                lds_wr(ad[0], sat_sum_u8(inp[0], hout[0]));
+                lds_wr(ad[1], sat_sum_u8(inp[1], hout[1]));
             } else {
             int Lh[NC];
 #pragma unroll
-            for (int k = 0; k < NC; k++) Lh[k] = lds[ad[k]];
+            for (int k = 0; k < NC; k++) Lh[k] = lds_rd(ad[k]);
             int xall = signs;
 #pragma unroll
             for (int k = 0; k < NC; k++) {
@@ -371,7 +379,7 @@ __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, con
                 const int sg = (xall ^ inp[k]) >> 31;
                 const int out = (other ^ sg) - sg;
                 hout[k] = out;
-                lds[ad[k]] = (uint8_t)sat_sum_u8(inp[k], out);
+                lds_wr(ad[k], sat_sum_u8(inp[k], out));
             }
             }
         }
@@ -399,7 +407,7 @@ __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, con
                 const int nl = sat_sum_u8(inp[k], out);
                 if (OWN_REG && k == DEG - 2) *carry = nl;
                 else if (PREV_REG && k == DEG - 1) spare = nl;
-                else if (!(LAYER0 && k == DEG - 1) || last_valid) lds[ad[k]] = (uint8_t)nl;
+                else if (!(LAYER0 && k == DEG - 1) || last_valid) lds_wr(ad[k], nl);
                 nm[k >> 2] |= (uint32_t)(min(max(out, -32), 31) + 128) << (8 * (k & 3));
             }
         }
@@ -447,8 +455,9 @@ __global__ __launch_bounds__(kThreads, MINW) void ldpc_layered_kernel(
     constexpr int MW = DMAX / 4; // message dwords per check (fixed per kernel variant)
     const int half = __builtin_amdgcn_readfirstlane(threadIdx.x >= kHalf ? 1 : 0); // wave-uniform, and the compiler knows it
     const int tid = threadIdx.x - half * kHalf;
-    const int lb = half * (int)half_lds_bytes(N);
-    uint8_t* lds = lds_all + lb;
+    const int lb_rel = half * (int)half_lds_bytes(N);
+    const int lb = lb_rel + lds_address_of(lds_all); // absolute LDS address of this frame's region
+    uint8_t* lds = lds_all + lb_rel;
     uint32_t* sv = reinterpret_cast<uint32_t*>(lds + N); // N % 8 == 0
     volatile int* flags = reinterpret_cast<volatile int*>(sv + (N / kM) * kSvWords); // [0] bad-or, [1] finished, [2] pre-test failed, [3] full test needed
     volatile int* other_flags = reinterpret_cast<volatile int*>(

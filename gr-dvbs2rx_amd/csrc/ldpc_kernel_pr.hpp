@@ -46,8 +46,9 @@ __global__ __launch_bounds__(kThreads, 6) void ldpc_layered_pr_kernel(
     constexpr int DMAX = 8, RS = rec_stride(DMAX), MW = 2;
     const int half = __builtin_amdgcn_readfirstlane(threadIdx.x >= kHalf ? 1 : 0);
     const int tid = threadIdx.x - half * kHalf;
-    const int lb = half * (int)pr_half_bytes(K);
-    uint8_t* lds = lds_all + lb;
+    const int lb_rel = half * (int)pr_half_bytes(K);
+    const int lb = lb_rel + lds_address_of(lds_all); // absolute LDS address of this frame's region
+    uint8_t* lds = lds_all + lb_rel;
     uint32_t* sv = reinterpret_cast<uint32_t*>(lds_all + 2 * pr_half_bytes(K));
     volatile int* flags_all = reinterpret_cast<volatile int*>(sv + (N / kM) * kSvWords);
     volatile int* flags = flags_all + 8 * half;        // [0] bad-or, [1] finished, [2] pre-test failed, [3] full test needed
