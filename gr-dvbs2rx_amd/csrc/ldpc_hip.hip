@@ -220,7 +220,14 @@ int LdpcDecoderHip::decode_device(const int8_t* d_llr_in, int n_frames, int max_
         double a[8] = {0};
         for (size_t r = 0; r < (size_t)n_frames * 6; r++) for (int c = 0; c < 8; c++) a[c] += (double)h[r * 8 + c];
         const double nr = (double)n_frames * 6;
-        fprintf(stderr, "[timing, 100MHz ticks per wave avg] load %.0f synd %.0f sweep %.0f (barrier %.0f body %.0f conflict-layers %.0f) iters %.1f synd-step1 %.0f\n", a[0]/nr, a[1]/nr, a[2]/nr, a[3]/nr, a[4]/nr, a[5]/nr, a[6]/nr, a[7]/nr);
+        if (getenv("DVBS2_TIMING_WAVES")) {
+            for (int w = 0; w < 6; w++) {
+                double b[8] = {0};
+                for (size_t fr = 0; fr < (size_t)n_frames; fr++) for (int c = 0; c < 8; c++) b[c] += (double)h[(fr * 6 + w) * 8 + c];
+                fprintf(stderr, "  wave %d: sweep %.0f barrier %.0f body %.0f conflict %.0f\n", w, b[2] / n_frames, b[3] / n_frames, b[4] / n_frames, b[5] / n_frames);
+            }
+        }
+        fprintf(stderr, "[timing, shader-clock cycles per wave avg] load %.0f synd %.0f sweep %.0f (barrier %.0f body %.0f conflict-layers %.0f) iters %.1f synd-step1 %.0f\n", a[0]/nr, a[1]/nr, a[2]/nr, a[3]/nr, a[4]/nr, a[5]/nr, a[6]/nr, a[7]/nr);
     }
     const int n_groups = (n_frames + G_ - 1) / G_;
     for (int round = 0;; round++) {
