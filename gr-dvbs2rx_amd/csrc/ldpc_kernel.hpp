@@ -207,8 +207,8 @@ __device__ __forceinline__ void check_node(uint8_t* __restrict__ lds /*the whole
 // a regular entry's bits are touched by exactly one row of the layer.
 // NC (2, 4 or 8) is the number of entries handled in P2: the hazard entries, rounded up with regular data entries
 // (moving a regular entry into the ordered part does not change the result).
-constexpr int kLaneChainRows = 424;                                   // 360 rows + one block of padding
-constexpr int kLaneChainWords = kLaneChainRows + kLaneChainRows / 4;  // per-row record (dword) + per-row log (byte)
+// LDS scratch of a lane chain with block size B: (360 + B) per-row records (dwords) + as many log bytes
+__host__ __device__ constexpr int lane_chain_words(int block) { return (kM + block) + (kM + block + 3) / 4; }
 constexpr int kLaneChainMaxDeg = 28;                                  // not instantiated for the big variants nor for the
                                                                       // 80-VGPR parity-in-records kernel (registers)
 constexpr int kMaxHazard = 8;
@@ -216,7 +216,7 @@ constexpr int kHazardWalk = 15; // header code: too many hazard entries, fall ba
 template <int DEG, int NC, bool LAYER0, bool PR = false, bool LAST = false>
 __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, const uint32_t* ent, int jj, int lb, bool work,
                                                   int block, const uint32_t* mw, uint32_t* nm, int own_in = 0, int* carry = nullptr,
-                                                  uint32_t* tab = nullptr /*kLaneChainWords of LDS scratch when the layer is a lane chain*/)
+                                                  uint32_t* tab = nullptr /*lane_chain_words(block) of LDS scratch when the layer is a lane chain*/)
 {
     constexpr bool OWN_REG = PR && !LAST;     // entry DEG-2 (see check_node)
     constexpr bool PREV_REG = PR && !LAYER0;  // entry DEG-1
@@ -276,7 +276,7 @@ __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, con
         //   C  chain lanes: incoming entry-1 LLR -> new entry-0 LLR of row r, incoming value logged      | barrier
         //   D  rows >= block: complete both outputs from the logged value; write entry 1; the last row of a chain
         //      also writes entry 0 (in the reference's order it is the final writer of that bit).
-        uint8_t* ulog = reinterpret_cast<uint8_t*>(tab + kLaneChainRows);
+        uint8_t* ulog = reinterpret_cast<uint8_t*>(tab + kM + block); // after the per-row records (360 rows + one block of padding)
         int chained = 0x80;
         const bool head = work && jj < block, body = work && jj >= block;
         if (head) {
