@@ -32,6 +32,9 @@ def init_from_env(backend=None):
 
 
 def barrier_sync():
+    """Device work done on this rank, then every rank arrived, then the barrier's own device work done."""
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
     if dist.is_initialized():
         dist.barrier()
     if torch.cuda.is_available():
