@@ -143,6 +143,8 @@ def main():
 
     world, rank, local = shard.init_from_env()  # nccl (= RCCL) rendezvous when WORLD_SIZE > 1
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if local >= torch.cuda.device_count():  # more ranks than GPUs: only for exercising the N > 1 path on a small box
+        local = local % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if capi.lib.dvbs2_device_count() < 1:

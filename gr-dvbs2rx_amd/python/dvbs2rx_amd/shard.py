@@ -23,7 +23,7 @@ def init_from_env(backend=None):
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1 and not dist.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            backend = os.environ.get("DVBS2_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         kw = {}
         if backend == "nccl":
             kw["device_id"] = torch.device("cuda", local)
@@ -41,15 +41,20 @@ def barrier_sync():
         torch.cuda.synchronize()
 
 
+def _reduce_device(device):
+    # gloo (CPU tests; or DVBS2_DIST_BACKEND=gloo to run several ranks on one GPU) reduces host tensors
+    return None if dist.is_initialized() and dist.get_backend() == "gloo" else device
+
+
 def max_over_ranks(value, device=None):
-    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=_reduce_device(device))
     if dist.is_initialized():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
 
 def sum_over_ranks(value, device=None):
-    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=_reduce_device(device))
     if dist.is_initialized():
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return float(t.item())
