@@ -209,8 +209,8 @@ int LdpcDecoderHip::decode_device(const int8_t* d_llr_in, int n_frames, int max_
             prof_ms_ += ms; prof_launches_++;
         }
     };
-    // bnl = 0 before the first update (layered_decoder.hh:27-31,149): offset-binary zero bytes
-    if (!pr_) HIP_RET(hipMemsetAsync(d_msgs_, 0x80, (size_t)n_frames * sched_.q * words_per_check_ * kMsgStride * 4, stream));
+    // bnl = 0 before the first update (layered_decoder.hh:27-31,149): both sweep kernels take zero messages in the first
+    // sweep of a fresh decode instead of reading them (no memset of the message records)
     launch(d_llr_in, nullptr, 1);
     HIP_RET(hipGetLastError());
     if (d_tdbg_) {

@@ -504,7 +504,17 @@ __global__ __launch_bounds__(kThreads, MINW) void ldpc_layered_kernel(
     __syncthreads();
     TSTAMP(tB); tm_load = tB - tA;
 
+    // Messages go through a buffer descriptor based at this frame's records: the per-lane offset (row * 4, plus the
+    // word offset) is loop-invariant and the per-layer offset is a scalar operand, so a message access costs no
+    // VALU address arithmetic (a flat 64-bit address costs two to four VALU instructions per access).
     uint32_t* msg_base = msgs + (size_t)(have_frame ? f : 0) * q * MW * kMsgStride;
+    const __amdgpu_buffer_rsrc_t mrs = __builtin_amdgcn_make_buffer_rsrc(msg_base, 0, q * MW * kMsgStride * 4, 0x00020000);
+    constexpr int kLayerBytes = MW * kMsgStride * 4;
+#define MSG_LD(soff, w, r4) __builtin_amdgcn_raw_buffer_load_b32(mrs, (r4), (soff) + (w) * (kMsgStride * 4), 0)
+#define MSG_ST(v, soff, w, r4) __builtin_amdgcn_raw_buffer_store_b32((v), mrs, (r4), (soff) + (w) * (kMsgStride * 4), 0)
+    // bnl = 0 before the first update (layered_decoder.hh:27-31,149): a frame's first sweep (it == 0, in the first pass or
+    // when a frame that stopped at once is resumed) takes offset-binary zero bytes instead of loading them -- no memset
+    // of the record area, no read traffic in sweep 0
     bool is_good = false;
 
     for (;;) {
@@ -604,10 +614,12 @@ __global__ __launch_bounds__(kThreads, MINW) void ldpc_layered_kernel(
         // keeps the whole sweep free of per-lane predicates: `work` is wave-uniform.
         const bool work = !finished;
         const int row = tid < kM ? tid : kM - 1;
+        const int row4 = row * 4;
+        const bool zero_msgs = it == 0; // uniform over the half
         uint32_t pre[MW]; // messages of the next layer for check tid, loaded one layer ahead
         if (work) {
 #pragma unroll
-            for (int w = 0; w < MW; w++) pre[w] = msg_base[w * kMsgStride + row];
+            for (int w = 0; w < MW; w++) pre[w] = zero_msgs ? 0x80808080u : MSG_LD(0, w, row4);
         }
         // Layer records are double-buffered in SGPRs: the scalar loads of layer i+1 are issued at the top of layer i
         // (an un-prefetched s_load at the head of every layer was a quarter of the sweep time). Small records are
@@ -634,7 +646,7 @@ __global__ __launch_bounds__(kThreads, MINW) void ldpc_layered_kernel(
             uint32_t* htab = ((hdr >> 12) & 1u) ? sv : nullptr; // lane-chain scratch: the sign-vector area is idle during a sweep
             const int block = (int)(hdr >> 16);
             const bool layer0 = (i == 0);
-            uint32_t* mp = msg_base + (size_t)i * MW * kMsgStride;
+            const int mso = i * kLayerBytes; // scalar byte offset of this layer's message records
             TSTAMP(tA);
             if (hdr & 0x8000u) __syncthreads();
             TSTAMP(tB); tm_bar += tB - tA;
@@ -645,13 +657,13 @@ __global__ __launch_bounds__(kThreads, MINW) void ldpc_layered_kernel(
                     uint32_t mw[MW], nm[MW];
 #pragma unroll
                     for (int w = 0; w < MW; w++) mw[w] = pre[w];
-                    if (i + 1 < q) {
+                    if (i + 1 < q && !zero_msgs) {
 #pragma unroll
-                        for (int w = 0; w < MW; w++) pre[w] = mp[(MW + w) * kMsgStride + row];
+                        for (int w = 0; w < MW; w++) pre[w] = MSG_LD(mso + kLayerBytes, w, row4);
                     }
                     DVBS2_DEG_SWITCH
 #pragma unroll
-                    for (int w = 0; w < MW; w++) mp[w * kMsgStride + jj] = nm[w];
+                    for (int w = 0; w < MW; w++) MSG_ST(nm[w], mso, w, row4);
                 }
                 TSTAMP(tC); tm_body += tC - tB;
             } else {
@@ -661,14 +673,14 @@ __global__ __launch_bounds__(kThreads, MINW) void ldpc_layered_kernel(
                     uint32_t mw[MW], nm[MW];
 #pragma unroll
                     for (int w = 0; w < MW; w++) mw[w] = work ? pre[w] : 0x80808080u;
-                    if (work && i + 1 < q) {
+                    if (work && i + 1 < q && !zero_msgs) {
 #pragma unroll
-                        for (int w = 0; w < MW; w++) pre[w] = mp[(MW + w) * kMsgStride + row];
+                        for (int w = 0; w < MW; w++) pre[w] = MSG_LD(mso + kLayerBytes, w, row4);
                     }
                     DVBS2_HAZ_SWITCH
                     if (work) {
 #pragma unroll
-                        for (int w = 0; w < MW; w++) mp[w * kMsgStride + jj] = nm[w];
+                        for (int w = 0; w < MW; w++) MSG_ST(nm[w], mso, w, row4);
                     }
                 } else {
                     // too many hazard entries: the first wave of the half walks the 360 checks alone in ascending
@@ -680,17 +692,17 @@ __global__ __launch_bounds__(kThreads, MINW) void ldpc_layered_kernel(
                             if (lane < chunk && jj < kM) {
                                 uint32_t mw[MW], nm[MW];
 #pragma unroll
-                                for (int w = 0; w < MW; w++) mw[w] = mp[w * kMsgStride + jj];
+                                for (int w = 0; w < MW; w++) mw[w] = zero_msgs ? 0x80808080u : MSG_LD(mso, w, jj * 4);
                                 DVBS2_DEG_SWITCH
 #pragma unroll
-                                for (int w = 0; w < MW; w++) mp[w * kMsgStride + jj] = nm[w];
+                                for (int w = 0; w < MW; w++) MSG_ST(nm[w], mso, w, jj * 4);
                             }
                         }
                     }
                     __syncthreads();
-                    if (work && i + 1 < q) {
+                    if (work && i + 1 < q && !zero_msgs) {
 #pragma unroll
-                        for (int w = 0; w < MW; w++) pre[w] = mp[(MW + w) * kMsgStride + row];
+                        for (int w = 0; w < MW; w++) pre[w] = MSG_LD(mso + kLayerBytes, w, row4);
                     }
                 }
                 TSTAMP(tC); tm_conf += tC - tB;
