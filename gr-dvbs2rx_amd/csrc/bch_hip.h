@@ -26,7 +26,8 @@ public:
     BchDecoderHip(int m, uint32_t prim_poly, int t, int n, int max_frames, int device);
     ~BchDecoderHip();
     bool ok() const { return err_.empty(); }
-    const std::string& error() const { return err_; }
+    // ok() reports the constructor; a failed call leaves its text in error() without disabling the handle
+    const std::string& error() const { return call_err_.empty() ? err_ : call_err_; }
     const BchCode& code() const { return code_; }
     int max_frames() const { return max_frames_; }
     // DEVICE pointers. d_cw: n_frames * n/8 bytes (first bit = x^(n-1), reference lib/bch.cc:436-449);
@@ -46,7 +47,8 @@ private:
     bool descramble_ = false;
     int n_cus_ = 0;
     size_t lds_bytes_ = 0;
-    std::string err_;
+    std::string err_;      // set by the constructor only
+    std::string call_err_; // last failed call
 };
 
 // the BBFRAME energy-dispersal sequence as packed bytes (host), lib/bbdescrambler_bb_impl.cc:51-65

@@ -15,6 +15,7 @@
 //               exponents [s+1, n+s] (lib/bch.cc:376-384, lib/gf.cc:376-401), all threads, LDS gathers.
 //   correction  message bits only, network bit order (lib/bch.cc:429-452).
 #include "bch_hip.h"
+#include "device_guard.h"
 #include <algorithm>
 #include <cstring>
 
@@ -72,6 +73,7 @@ bool BchCode::build(int m_, uint32_t prim_poly, int t_, int n_, std::string* err
 
 constexpr int kBchThreads = 1024;
 constexpr int kMaxT = 12;
+constexpr int kBchWorkWords = 640; // dwords of per-workgroup scratch between the antilog table and the codeword bytes
 
 struct BchArgs {
     const uint16_t* antilog; const uint16_t* log; const uint16_t* quad;
@@ -100,11 +102,15 @@ __global__ __launch_bounds__(kBchThreads) void bch_decode_kernel(BchArgs a)
     uint32_t* lsig = w + 32;    // [t+1] log of sigma coefficients, 0xffffffff for zero
     uint32_t* roots = w + 64;   // [<=16] root exponents found by the Chien search
     int* ctl = reinterpret_cast<int*>(w + 96); // [0] degree, [1] nroots, [2] mode, [3] status
-    uint32_t (*sg)[kMaxT + 3] = reinterpret_cast<uint32_t (*)[kMaxT + 3]>(w + 128); // Berlekamp table rows
-    int* dg = reinterpret_cast<int*>(w + 368);
-    uint32_t* d = w + 384;
-    int* two_mu = reinterpret_cast<int*>(w + 400);
-    uint8_t* cwl = reinterpret_cast<uint8_t*>(w + 512);                // codeword bytes
+    // Berlekamp table rows at their FULL width: row mu + 1 can reach degree 2 mu + 1 (S_1 .. S_2mu = 0, S_2mu+1 != 0), so the
+    // last row can reach 2t - 1 > t; the reference keeps every coefficient (gf2m_poly, lib/bch.cc:286-297) and "degree > t"
+    // (lib/bch.cc:313-314) must be decided on the true degree
+    constexpr int kSigW = 2 * kMaxT + 4;
+    int* dg = reinterpret_cast<int*>(w + 104);
+    uint32_t* d = w + 120;
+    int* two_mu = reinterpret_cast<int*>(w + 136);
+    uint32_t (*sg)[kSigW] = reinterpret_cast<uint32_t (*)[kSigW]>(w + 160); // [kMaxT + 3][kSigW] = 420 dwords
+    uint8_t* cwl = reinterpret_cast<uint8_t*>(w + kBchWorkWords);       // codeword bytes
 
     for (uint32_t i = tid; i < P; i += kBchThreads) al[i] = a.antilog[i];
 
@@ -156,7 +162,7 @@ __global__ __launch_bounds__(kBchThreads) void bch_decode_kernel(BchArgs a)
                 // even syndromes: S_2i = S_i^2
                 for (int i = 2; i <= 2 * t; i += 2) S[i - 1] = mul(S[i / 2 - 1], S[i / 2 - 1]);
                 // ---- simplified Berlekamp (lib/bch.cc:225-304) ----
-                for (int r = 0; r < t + 3; r++) for (int c = 0; c < t + 3; c++) sg[r][c] = 0;
+                for (int r = 0; r < t + 3; r++) for (int c = 0; c < kSigW; c++) sg[r][c] = 0;
                 two_mu[0] = -1;
                 for (int i = 0; i < t + 1; i++) two_mu[i + 1] = 2 * i;
                 sg[0][0] = 1; dg[0] = 0; sg[1][0] = 1; dg[1] = 0;
@@ -168,19 +174,17 @@ __global__ __launch_bounds__(kBchThreads) void bch_decode_kernel(BchArgs a)
                     uint32_t dr = S[tm];
                     for (int j = 1; j <= dg[row]; j++) if (sg[row][j]) dr ^= mul(sg[row][j], S[tm - j]);
                     d[row] = dr;
-                    if (dr == 0) { for (int c = 0; c < t + 3; c++) sg[row + 1][c] = sg[row][c]; dg[row + 1] = dg[row]; }
+                    if (dr == 0) { for (int c = 0; c < kSigW; c++) sg[row + 1][c] = sg[row][c]; dg[row + 1] = dg[row]; }
                     else {
                         int row_rho = 0, max_diff = -2;
                         for (int j = row - 1; j >= 0; j--)
                             if (d[j] != 0) { const int diff = two_mu[j] - dg[j]; if (diff > max_diff) { max_diff = diff; row_rho = j; } }
                         const int shift = tm - two_mu[row_rho];
                         const uint32_t coef = mul(dr, inv(d[row_rho]));
-                        for (int c = 0; c < t + 3; c++) sg[row + 1][c] = sg[row][c];
+                        for (int c = 0; c < kSigW; c++) sg[row + 1][c] = sg[row][c];
                         int top = dg[row];
-                        for (int j = 0; j <= dg[row_rho]; j++)
-                            if (j + shift < t + 3) sg[row + 1][j + shift] ^= mul(coef, sg[row_rho][j]);
+                        for (int j = 0; j <= dg[row_rho]; j++) sg[row + 1][j + shift] ^= mul(coef, sg[row_rho][j]); // j + shift <= 2t - 1
                         if (dg[row_rho] + shift > top) top = dg[row_rho] + shift;
-                        if (top > t + 2) top = t + 2;
                         while (top >= 0 && sg[row + 1][top] == 0) top--;
                         dg[row + 1] = top;
                     }
@@ -259,7 +263,7 @@ BchDecoderHip::BchDecoderHip(int m, uint32_t prim_poly, int t, int n, int max_fr
 {
     if (!code_.build(m, prim_poly, t, n, &err_)) return;
     if (code_.n % 8 || code_.k % 8) { err_ = "u8 array messages are only supported for n and k multiple of 8."; return; } // lib/bch.cc:19-24
-    if (max_frames_ < 1) { err_ = "bad max_frames"; return; }
+    if (max_frames_ < 1 || max_frames_ > 65535) { err_ = "max_frames must be in 1..65535 (frames are one launch dimension)"; return; }
 #define HIP_OK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { err_ = std::string(#x) + ": " + hipGetErrorString(e_); return; } } while (0)
     HIP_OK(hipSetDevice(device_));
     hipDeviceProp_t pr;
@@ -271,7 +275,7 @@ BchDecoderHip::BchDecoderHip(int m, uint32_t prim_poly, int t, int n, int max_fr
     HIP_OK(hipMemcpy(d_antilog_, code_.antilog.data(), code_.antilog.size() * 2, hipMemcpyHostToDevice));
     HIP_OK(hipMemcpy(d_log_, code_.log.data(), code_.log.size() * 2, hipMemcpyHostToDevice));
     HIP_OK(hipMemcpy(d_quad_, code_.quad.data(), code_.quad.size() * 2, hipMemcpyHostToDevice));
-    lds_bytes_ = (((size_t)code_.P * 2 + 15) & ~(size_t)15) + 512 * 4 + (size_t)((code_.n / 8 + 15) & ~15);
+    lds_bytes_ = (((size_t)code_.P * 2 + 15) & ~(size_t)15) + kBchWorkWords * 4 + (size_t)((code_.n / 8 + 15) & ~15);
     HIP_OK(hipFuncSetAttribute((const void*)bch_decode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes_));
 #undef HIP_OK
 }
@@ -294,12 +298,14 @@ void bb_derandomise_sequence(uint8_t* seq, int n_bytes)
 int BchDecoderHip::set_descramble(bool enable)
 {
     if (!ok()) return -1;
-    if (hipSetDevice(device_) != hipSuccess) { err_ = "hipSetDevice failed"; return -1; }
+    call_err_.clear();
+    DeviceGuard dev_guard(device_);
+    if (!dev_guard.ok) { call_err_ = "hipSetDevice failed"; return -1; }
     if (enable && !d_scramble_) {
         std::vector<uint8_t> seq(code_.k / 8);
         bb_derandomise_sequence(seq.data(), (int)seq.size());
         if (hipMalloc(&d_scramble_, seq.size()) != hipSuccess ||
-            hipMemcpy(d_scramble_, seq.data(), seq.size(), hipMemcpyHostToDevice) != hipSuccess) { err_ = "descramble sequence upload failed"; return -1; }
+            hipMemcpy(d_scramble_, seq.data(), seq.size(), hipMemcpyHostToDevice) != hipSuccess) { call_err_ = "descramble sequence upload failed"; return -1; }
     }
     descramble_ = enable;
     return 0;
@@ -315,9 +321,11 @@ BchDecoderHip::~BchDecoderHip()
 int BchDecoderHip::decode_device(const uint8_t* d_cw, int n_frames, uint8_t* d_msg, int32_t* d_corr, hipStream_t stream)
 {
     if (!ok()) return -1;
-    if (n_frames < 0 || n_frames > max_frames_) { err_ = "n_frames exceeds max_frames"; return -1; }
+    call_err_.clear();
+    if (n_frames < 0 || n_frames > max_frames_) { call_err_ = "n_frames exceeds max_frames"; return -1; }
     if (n_frames == 0) return 0;
-    if (hipSetDevice(device_) != hipSuccess) { err_ = "hipSetDevice failed"; return -1; }
+    DeviceGuard dev_guard(device_);
+    if (!dev_guard.ok) { call_err_ = "hipSetDevice failed"; return -1; }
     BchArgs a;
     a.antilog = d_antilog_; a.log = d_log_; a.quad = d_quad_; a.cw = d_cw; a.msg = d_msg; a.corr = d_corr;
     a.descramble = descramble_ ? d_scramble_ : nullptr;
@@ -325,7 +333,7 @@ int BchDecoderHip::decode_device(const uint8_t* d_cw, int n_frames, uint8_t* d_m
     const int grid = std::min(n_frames, std::max(1, n_cus_));
     hipLaunchKernelGGL(bch_decode_kernel, dim3(grid), dim3(kBchThreads), lds_bytes_, stream, a);
     hipError_t e = hipGetLastError();
-    if (e != hipSuccess) { err_ = std::string("bch kernel launch: ") + hipGetErrorString(e); return -1; }
+    if (e != hipSuccess) { call_err_ = std::string("bch kernel launch: ") + hipGetErrorString(e); return -1; }
     return 0;
 }
 

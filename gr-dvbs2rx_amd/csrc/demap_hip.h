@@ -13,7 +13,8 @@ public:
     // QPSK or 8PSK only ("Unsupported constellation" otherwise, :70-72), 8PSK column order by rate (:50-69).
     DemapperHip(int framesize, int rate, int constellation, int max_frames, int device);
     bool ok() const { return err_.empty(); }
-    const std::string& error() const { return err_; }
+    // ok() reports the constructor; a failed call leaves its text in error() without disabling the handle
+    const std::string& error() const { return call_err_.empty() ? err_ : call_err_; }
     int n_llr() const { return n_llr_; }
     int n_mod() const { return n_mod_; }
     int n_syms() const { return n_llr_ / n_mod_; }
@@ -29,7 +30,8 @@ public:
 
 private:
     int n_llr_ = 0, n_mod_ = 0, order_ = 0, constellation_ = 0, max_frames_ = 0, device_ = 0;
-    std::string err_;
+    std::string err_;      // set by the constructor only
+    std::string call_err_; // last failed call
 };
 
 } // namespace dvbs2

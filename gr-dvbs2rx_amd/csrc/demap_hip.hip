@@ -10,6 +10,7 @@
 #include <cmath>
 #include "../../include/dvbs2_fec_hip.h"
 
+#include "device_guard.h"
 namespace dvbs2 {
 
 __device__ __forceinline__ int8_t sat8_rint(float v)
@@ -115,15 +116,17 @@ DemapperHip::DemapperHip(int framesize, int rate, int constellation, int max_fra
         else if (rate == 26 || rate == 28 || rate == 38 || rate == 39 || rate == 19) order_ = 2; // "102"
         else order_ = 0;                                                                         // "012"
     } else { err_ = "Unsupported constellation"; return; }
-    if (max_frames_ < 1) { err_ = "bad max_frames"; return; }
+    if (max_frames_ < 1 || max_frames_ > 65535) { err_ = "max_frames must be in 1..65535 (frames are one launch dimension)"; return; }
 }
 
 int DemapperHip::soft_device(const float* d_syms, int n_frames, const float* d_n0, int n0_count, int8_t* d_llr, hipStream_t stream)
 {
     if (!ok()) return -1;
-    if (n_frames < 0 || n_frames > max_frames_) { err_ = "n_frames exceeds max_frames"; return -1; }
+    call_err_.clear();
+    if (n_frames < 0 || n_frames > max_frames_) { call_err_ = "n_frames exceeds max_frames"; return -1; }
     if (n_frames == 0) return 0;
-    if (hipSetDevice(device_) != hipSuccess) { err_ = "hipSetDevice failed"; return -1; }
+    DeviceGuard dev_guard(device_);
+    if (!dev_guard.ok) { call_err_ = "hipSetDevice failed"; return -1; }
     if (constellation_ == DVBS2_MOD_QPSK) {
         const int quads = n_llr_ / 4;
         hipLaunchKernelGGL(demap_qpsk_kernel, dim3((quads + 255) / 256, n_frames), dim3(256), 0, stream,
@@ -138,16 +141,18 @@ int DemapperHip::soft_device(const float* d_syms, int n_frames, const float* d_n
                            reinterpret_cast<const float2*>(d_syms), d_n0, n0_count, d_llr, rows, ra0, ra1, ra2, rr, ri);
     }
     hipError_t e = hipGetLastError();
-    if (e != hipSuccess) { err_ = std::string("demap kernel launch: ") + hipGetErrorString(e); return -1; }
+    if (e != hipSuccess) { call_err_ = std::string("demap kernel launch: ") + hipGetErrorString(e); return -1; }
     return 0;
 }
 
 int DemapperHip::snr_device(const float* d_syms, const int8_t* d_ref_llr, int n_frames, float* d_snr, hipStream_t stream)
 {
     if (!ok()) return -1;
-    if (n_frames < 0 || n_frames > max_frames_) { err_ = "n_frames exceeds max_frames"; return -1; }
+    call_err_.clear();
+    if (n_frames < 0 || n_frames > max_frames_) { call_err_ = "n_frames exceeds max_frames"; return -1; }
     if (n_frames == 0) return 0;
-    if (hipSetDevice(device_) != hipSuccess) { err_ = "hipSetDevice failed"; return -1; }
+    DeviceGuard dev_guard(device_);
+    if (!dev_guard.ok) { call_err_ = "hipSetDevice failed"; return -1; }
     const float rr = (float)std::cos(-M_PI / 8), ri = (float)std::sin(-M_PI / 8);
     const int rows = n_syms();
     int ra0 = 0, ra1 = rows, ra2 = 2 * rows;
@@ -156,7 +161,7 @@ int DemapperHip::snr_device(const float* d_syms, const int8_t* d_ref_llr, int n_
     hipLaunchKernelGGL(demap_snr_kernel, dim3(n_frames), dim3(256), 0, stream,
                        reinterpret_cast<const float2*>(d_syms), d_ref_llr, d_snr, rows, constellation_, ra0, ra1, ra2, rr, ri);
     hipError_t e = hipGetLastError();
-    if (e != hipSuccess) { err_ = std::string("snr kernel launch: ") + hipGetErrorString(e); return -1; }
+    if (e != hipSuccess) { call_err_ = std::string("snr kernel launch: ") + hipGetErrorString(e); return -1; }
     return 0;
 }
 

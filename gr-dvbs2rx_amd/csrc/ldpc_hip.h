@@ -15,7 +15,8 @@ public:
     LdpcDecoderHip(const LdpcTableDesc* table, int out_bits_message, int group_size, int max_frames, int device);
     ~LdpcDecoderHip();
     bool ok() const { return err_.empty(); }
-    const std::string& error() const { return err_; }
+    // ok() reports the constructor; a failed call leaves its text in error() without disabling the handle
+    const std::string& error() const { return call_err_.empty() ? err_ : call_err_; }
 
     int N() const { return sched_.N; }
     int K() const { return sched_.K; }
@@ -64,7 +65,8 @@ private:
     double prof_ms_ = 0;
     int prof_launches_ = 0;
     hipEvent_t ev0_ = nullptr, ev1_ = nullptr;
-    std::string err_;
+    std::string err_;      // set by the constructor only
+    std::string call_err_; // last failed call
 };
 
 } // namespace dvbs2

@@ -18,6 +18,7 @@
 #include "ldpc_hip.h"
 #include "ldpc_kernel.hpp"
 #include "ldpc_kernel_pr.hpp"
+#include "device_guard.h"
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -26,7 +27,7 @@
 namespace dvbs2 {
 
 #define HIP_OK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { err_ = std::string(#x) + ": " + hipGetErrorString(e_); return; } } while (0)
-#define HIP_RET(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { err_ = std::string(#x) + ": " + hipGetErrorString(e_); return -1; } } while (0)
+#define HIP_RET(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { call_err_ = std::string(#x) + ": " + hipGetErrorString(e_); return -1; } } while (0)
 
 // Per-group stopping rule of one reference SIMD batch: while (bad(any lane) && --trials >= 0) update(all lanes)
 // (layered_decoder.hh:153). After a pass, every frame f sits at iters[f] updates with good[f] known there.
@@ -78,7 +79,7 @@ LdpcDecoderHip::LdpcDecoderHip(const LdpcTableDesc* table, int out_bits_message,
     : out_bits_message_(out_bits_message), G_(group_size), max_frames_(max_frames), device_(device)
 {
     if (!compile_ldpc_schedule(table, &sched_)) { err_ = "unknown or inconsistent LDPC table"; return; }
-    if (G_ < 1 || max_frames_ < 1) { err_ = "bad group_size/max_frames"; return; }
+    if (G_ < 1 || max_frames_ < 1 || max_frames_ > 65535) { err_ = "bad group_size/max_frames (max_frames 1..65535: frames are one launch dimension)"; return; }
     if (out_bits_message_ <= 0 || out_bits_message_ > sched_.N || out_bits_message_ % 8) { err_ = "bad message length"; return; }
     int degmax = 0, degmin = 1000;
     for (const LdpcLayer& L : sched_.layers) { degmax = std::max(degmax, L.cnt + 2); degmin = std::min(degmin, L.cnt + 2); }
@@ -184,10 +185,12 @@ int LdpcDecoderHip::decode_device(const int8_t* d_llr_in, int n_frames, int max_
                                   uint8_t* d_bits_out, int8_t* d_llr_out, int32_t* d_ret, hipStream_t stream)
 {
     if (!ok()) return -1;
-    if (n_frames < 0 || n_frames > max_frames_) { err_ = "n_frames exceeds max_frames"; return -1; }
+    call_err_.clear();
+    if (n_frames < 0 || n_frames > max_frames_) { call_err_ = "n_frames exceeds max_frames"; return -1; }
     if (n_frames == 0) return 0;
-    if (max_trials < 0) { err_ = "max_trials < 0"; return -1; }
-    HIP_RET(hipSetDevice(device_));
+    if (max_trials < 0) { call_err_ = "max_trials < 0"; return -1; }
+    DeviceGuard dev_guard(device_);
+    if (!dev_guard.ok) { call_err_ = "hipSetDevice failed"; return -1; }
     const size_t lds_bytes = lds_bytes_;
     auto launch = [&](const int8_t* in, const int* target, int stop_on_good) {
         if (profiling_) (void)hipEventRecord(ev0_, stream);
@@ -237,7 +240,7 @@ int LdpcDecoderHip::decode_device(const int8_t* d_llr_in, int n_frames, int max_
         HIP_RET(hipMemcpyAsync(h_flag_, d_flag_, 4, hipMemcpyDeviceToHost, stream));
         HIP_RET(hipStreamSynchronize(stream));
         if (*h_flag_ == 0) break;
-        if (round > 2 * max_trials + 2) { err_ = "group resolution did not converge"; return -1; }
+        if (round > 2 * max_trials + 2) { call_err_ = "group resolution did not converge"; return -1; }
         launch(nullptr, d_target_, 0);
         HIP_RET(hipGetLastError());
     }

@@ -19,7 +19,8 @@ public:
     PlPayloadHip(int gold_code, int n_slots, int has_pilots, int max_frames, int device);
     ~PlPayloadHip();
     bool ok() const { return err_.empty(); }
-    const std::string& error() const { return err_; }
+    // ok() reports the constructor; a failed call leaves its text in error() without disabling the handle
+    const std::string& error() const { return call_err_.empty() ? err_ : call_err_; }
     int n_slots() const { return n_slots_; }
     int n_pilots() const { return n_pilots_; }
     int payload_len() const { return n_slots_ * 90 + n_pilots_ * 36; }
@@ -34,7 +35,8 @@ public:
 private:
     int n_slots_, n_pilots_, has_pilots_, max_frames_, device_;
     uint8_t* d_rn_ = nullptr;
-    std::string err_;
+    std::string err_;      // set by the constructor only
+    std::string call_err_; // last failed call
 };
 
 } // namespace dvbs2

@@ -2,6 +2,7 @@
 #include "plpayload_hip.h"
 #include <cmath>
 
+#include "device_guard.h"
 namespace dvbs2 {
 
 void pl_scrambling_rn(int gold_code, uint8_t* rn, int n)
@@ -52,7 +53,7 @@ PlPayloadHip::PlPayloadHip(int gold_code, int n_slots, int has_pilots, int max_f
     n_pilots_ = has_pilots_ ? ((n_slots_ - 1) >> 4) : 0; // lib/pl_signaling.cc:51
     if (n_slots_ < 36 || n_slots_ > 360) { err_ = "n_slots out of range (36..360)"; return; } // lib/pl_defs.h:19-20
     if (gold_code < 0 || gold_code >= (1 << 18) - 1) { err_ = "gold code out of range"; return; }
-    if (max_frames_ < 1) { err_ = "bad max_frames"; return; }
+    if (max_frames_ < 1 || max_frames_ > 65535) { err_ = "max_frames must be in 1..65535 (frames are one launch dimension)"; return; }
     std::vector<uint8_t> rn(payload_len());
     pl_scrambling_rn(gold_code, rn.data(), (int)rn.size());
     if (hipSetDevice(device_) != hipSuccess || hipMalloc(&d_rn_, rn.size()) != hipSuccess ||
@@ -65,14 +66,16 @@ int PlPayloadHip::process_device(const float* d_payload, int n_frames, const flo
                                  const int32_t* d_coarse_corrected, const float* d_pilot_phase, float* d_out, hipStream_t stream)
 {
     if (!ok()) return -1;
-    if (n_frames < 0 || n_frames > max_frames_) { err_ = "n_frames exceeds max_frames"; return -1; }
+    call_err_.clear();
+    if (n_frames < 0 || n_frames > max_frames_) { call_err_ = "n_frames exceeds max_frames"; return -1; }
     if (n_frames == 0) return 0;
-    if (hipSetDevice(device_) != hipSuccess) { err_ = "hipSetDevice failed"; return -1; }
+    DeviceGuard dev_guard(device_);
+    if (!dev_guard.ok) { call_err_ = "hipSetDevice failed"; return -1; }
     hipLaunchKernelGGL(pl_payload_kernel, dim3((xfecframe_len() + 255) / 256, n_frames), dim3(256), 0, stream,
                        reinterpret_cast<const float2*>(d_payload), d_rn_, d_plheader_phase, d_phase_inc, d_coarse_corrected,
                        d_pilot_phase, reinterpret_cast<float2*>(d_out), n_slots_, n_pilots_, has_pilots_);
     hipError_t e = hipGetLastError();
-    if (e != hipSuccess) { err_ = std::string("pl payload kernel launch: ") + hipGetErrorString(e); return -1; }
+    if (e != hipSuccess) { call_err_ = std::string("pl payload kernel launch: ") + hipGetErrorString(e); return -1; }
     return 0;
 }
 

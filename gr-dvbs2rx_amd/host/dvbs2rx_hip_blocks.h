@@ -29,7 +29,7 @@ namespace dvbs2rx_hip {
 // enumerations with the reference's values (dvb_config.h)
 enum dvb_standard_t { STANDARD_DVBS2 = 0, STANDARD_DVBT2 };
 enum dvb_framesize_t { FECFRAME_SHORT = 0, FECFRAME_NORMAL, FECFRAME_MEDIUM };
-enum dvb_constellation_t { MOD_QPSK = 0, MOD_16QAM, MOD_8PSK = 2 };
+enum dvb_constellation_t { MOD_QPSK = 0, MOD_16QAM, MOD_64QAM, MOD_256QAM, MOD_8PSK, MOD_8APSK, MOD_16APSK, MOD_8_8APSK, MOD_32APSK };
 enum dvb_outputmode_t { OM_CODEWORD = 0, OM_MESSAGE };
 enum dvb_infomode_t { INFO_OFF = 0, INFO_ON };
 typedef int dvb_code_rate_t; // use dvbs2_rate_from_name("C1_2") or the reference's enumerator value

@@ -23,7 +23,7 @@ OK, EINVAL, EDEVICE, ESIZE = 0, -1, -2, -3
 STANDARD_DVBS2, STANDARD_DVBT2 = 0, 1
 FECFRAME_SHORT, FECFRAME_NORMAL, FECFRAME_MEDIUM = 0, 1, 2
 OM_CODEWORD, OM_MESSAGE = 0, 1
-MOD_QPSK, MOD_8PSK = 0, 2
+MOD_QPSK, MOD_8PSK = 0, 4
 
 
 class FecInfo(C.Structure):

@@ -26,8 +26,14 @@ def init_from_env(backend=None):
             backend = os.environ.get("DVBS2_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         kw = {}
         if backend == "nccl":
-            kw["device_id"] = torch.device("cuda", local)
+            # one rank per GPU is the deployment; more ranks than GPUs (a one-GPU test box) wrap around here, BEFORE the
+            # device is handed to the process group, and RCCL then refuses two ranks on one device unless the caller
+            # chose DVBS2_DIST_BACKEND=gloo for that experiment
+            ndev = max(1, torch.cuda.device_count())
+            kw["device_id"] = torch.device("cuda", local % ndev)
         dist.init_process_group(backend=backend, **kw)
+    if torch.cuda.is_available():
+        local = local % max(1, torch.cuda.device_count())
     return world, rank, local
 
 

@@ -39,10 +39,11 @@ extern "C" {
 /* dvb_outputmode_t */
 #define DVBS2_OM_CODEWORD 0
 #define DVBS2_OM_MESSAGE 1
-/* dvb_constellation_t (only the two the reference demapper supports,
- * lib/xfecframe_demapper_cb_impl.cc:45-72) */
+/* dvb_constellation_t (dvb_config.h:80-101: QPSK 0, 16QAM 1, 64QAM 2, 256QAM 3, 8PSK 4, ...); only the two the
+ * reference demapper supports are accepted (lib/xfecframe_demapper_cb_impl.cc:45-72). Pinned against the reference
+ * header by tests/test_oracle_kat.py::test_enums_match_reference (tests/golden/dvb_config_enums.json). */
 #define DVBS2_MOD_QPSK 0
-#define DVBS2_MOD_8PSK 2
+#define DVBS2_MOD_8PSK 4
 
 const char* dvbs2_last_error(void);
 int dvbs2_device_count(void);

@@ -82,6 +82,58 @@ def ref_ldpc():
     return _ref
 
 
+_ref_bch = None
+
+
+def ref_bch():
+    """ctypes handle of oracle/_ref/libdvbs2_ref_bch.so (the genuine reference BCH codec), or None."""
+    global _ref_bch
+    if _ref_bch is None:
+        p = os.path.join(ORACLE_DIR, "_ref", "libdvbs2_ref_bch.so")
+        if not os.path.exists(p):
+            return None
+        r = C.CDLL(p)
+        r.ref_bch_new.argtypes = [C.c_uint32, C.c_int, C.c_int]
+        r.ref_bch_new.restype = C.c_void_p
+        r.ref_bch_free.argtypes = [C.c_void_p]
+        r.ref_bch_k.argtypes = [C.c_void_p]
+        r.ref_bch_n.argtypes = [C.c_void_p]
+        r.ref_bch_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        r.ref_bch_encode.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        _ref_bch = r
+    return _ref_bch
+
+
+class RefBch:
+    """The genuine reference bch_codec<uint32_t, bitset256_t> (container build, oracle/_ref). decode() returns the
+    reference's return value, or -2 where it throws."""
+
+    def __init__(self, prim_poly, t, n=0):
+        self.r = ref_bch()
+        assert self.r is not None, "oracle/_ref/libdvbs2_ref_bch.so absent"
+        self.h = self.r.ref_bch_new(prim_poly, t, n)
+        assert self.h, "reference constructor threw"
+        self.n, self.k = self.r.ref_bch_n(self.h), self.r.ref_bch_k(self.h)
+
+    def decode(self, cw):
+        cw = np.ascontiguousarray(cw, np.uint8).reshape(-1, self.n // 8)
+        msg = np.zeros((cw.shape[0], self.k // 8), np.uint8)
+        ret = [self.r.ref_bch_decode(self.h, ptr(cw[f]), ptr(msg[f])) for f in range(cw.shape[0])]
+        return msg, ret
+
+    def encode(self, msg):
+        msg = np.ascontiguousarray(msg, np.uint8).reshape(-1, self.k // 8)
+        cw = np.zeros((msg.shape[0], self.n // 8), np.uint8)
+        for f in range(msg.shape[0]):
+            self.r.ref_bch_encode(self.h, ptr(msg[f]), ptr(cw[f]))
+        return cw
+
+    def close(self):
+        if self.h:
+            self.r.ref_bch_free(self.h)
+            self.h = None
+
+
 def ptr(a):
     return a.ctypes.data_as(C.c_void_p)
 
@@ -224,6 +276,21 @@ class OracleBch:
         for f in range(cw.shape[0]):
             ret[f] = self.o.oracle_bch_decode_bytes(self.h, ptr(cw[f]), ptr(msg[f]))
         return msg, ret
+
+
+def bch_golden_input(codec, n, k, case):
+    """Received word of one tests/golden/bch_golden.json case. codec: anything with encode_bytes()/encode() (the
+    systematic encoder is pinned by the reference's own KATs and by the committed sha_in)."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bch_craft
+    if "exps" in case:
+        return bch_craft.word_from_exponents(n, case["exps"])
+    if case.get("garbage"):
+        return np.random.default_rng(case["seed"]).integers(0, 256, n // 8, dtype=np.uint8)
+    msg = np.random.default_rng(case["seed"]).integers(0, 256, (1, k // 8), dtype=np.uint8)
+    cw = codec.encode(msg)[0] if hasattr(codec, "encode") else codec.encode_bytes(msg)[0]
+    return flip_bits(cw, case["flips"])
 
 
 BCH_FIELDS = {1: (16, 0b10000000000101101), 0: (14, 0b100000000101011), 2: (15, 0b1000000000101101)}  # by framesize id

@@ -105,6 +105,46 @@ def test_bch_failure_region_matches_oracle():
     dec.close()
 
 
+def test_bch_reference_digests_on_gpu():
+    """The kernel against digests of the GENUINE reference codec (tests/golden/bch_golden.json <- tools/gen_bch_golden.py):
+    every BASELINE (n, t) x {0, 1, 2, 3, t, t+1, 40, 100 errors, parity only, garbage} plus words crafted to reach BOTH
+    places where the reference throws: a degree-2 locator without roots (lib/bch.cc:359-367 -> lib/gf.h:110) and an
+    error location >= n on the shortened code (lib/bch.cc:443-444), reported as -2."""
+    import json, os
+    gold = json.load(open(os.path.join(T.ROOT, "tests", "golden", "bch_golden.json")))
+    for code in gold["codes"]:
+        m, prim = T.BCH_FIELDS[code["framesize"]]
+        ob = T.OracleBch(m, prim, code["t"], code["n"])
+        rx = np.stack([T.bch_golden_input(ob, code["n"], code["k"], c) for c in code["cases"]])
+        dec = BchDecoder(framesize=code["framesize"], rate=code["rate"], max_frames=len(rx))
+        out, ret = dec.work(rx)
+        assert ret.tolist() == [c["ret"] for c in code["cases"]], code["rate"]
+        for i, c in enumerate(code["cases"]):
+            assert T.sha(rx[i]) == c["sha_in"] and T.sha(out[i]) == c["sha_out"], (code["rate"], c["name"])
+        assert ret.tolist().count(-2) == 2
+        dec.close()
+
+
+def test_bch_vs_genuine_reference_live():
+    """Random words incl. > t errors and garbage against the genuine codec when oracle/_ref holds it."""
+    if T.ref_bch() is None:
+        pytest.skip("oracle/_ref/libdvbs2_ref_bch.so absent")
+    rng = np.random.default_rng(5)
+    for fs, rate in ((capi.FECFRAME_SHORT, "C1_4"), (capi.FECFRAME_NORMAL, "C1_2"), (capi.FECFRAME_NORMAL, "C9_10")):
+        fi = get_fec_info(capi.STANDARD_DVBS2, fs, rate)
+        n, k, t = fi["bch_n"], fi["bch_k"], fi["bch_t"]
+        ref = T.RefBch(T.BCH_FIELDS[fs][1], t, n)
+        msg = rng.integers(0, 256, (48, k // 8), dtype=np.uint8)
+        cw = ref.encode(msg)
+        rx = np.stack([T.flip_bits(cw[i], rng.choice(n, int(rng.integers(0, 4 * t)), replace=False)) for i in range(40)] +
+                      [rng.integers(0, 256, n // 8, dtype=np.uint8) for _ in range(8)])
+        want, wret = ref.decode(rx)
+        dec = BchDecoder(framesize=fs, rate=rate, max_frames=len(rx))
+        out, ret = dec.work(rx)
+        assert ret.tolist() == wret and np.array_equal(out, want)
+        dec.close(); ref.close()
+
+
 def test_bch_small_field_kats_on_gpu():
     """(32, 8) t=4 shortened code over GF(2^6) (lib/qa_bch.cc:539-604), all 1- and 2-bit patterns."""
     ob = T.OracleBch(6, 0b1000011, 4, 32)

@@ -200,3 +200,77 @@ def test_create_fails_loudly_without_device_or_with_bad_args():
         assert capi.lib.dvbs2_demap_create(C.byref(h), 1, 3, 0, 8, 0) == capi.EDEVICE
     assert capi.lib.dvbs2_ldpc_create(C.byref(h), 0, 1, 50, 32, 8, 0) == capi.EINVAL  # C_OTHER
     assert capi.lib.dvbs2_ldpc_create_table(C.byref(h), b"NOPE", 8, 1, 1, 0) == capi.EINVAL
+
+
+def test_enums_match_reference():
+    """The C ABI, the ctypes binding and the C++ host mirror take the reference's enumerator values
+    (include/gnuradio/dvbs2rx/dvb_config.h, transcribed as data by tools/gen_enum_golden.py)."""
+    import json, re
+    gold = json.load(open(os.path.join(T.ROOT, "tests", "golden", "dvb_config_enums.json")))["enums"]
+    hdr = open(os.path.join(T.ROOT, "include", "dvbs2_fec_hip.h")).read()
+    macros = {m.group(1): int(m.group(2)) for m in re.finditer(r"#define\s+DVBS2_(\w+)\s+(-?\d+)\s", hdr)}
+    flat = {}
+    for e in gold.values():
+        flat.update(e)
+    checked = 0
+    for name in ("STANDARD_DVBS2", "STANDARD_DVBT2", "FECFRAME_SHORT", "FECFRAME_NORMAL", "FECFRAME_MEDIUM",
+                 "OM_CODEWORD", "OM_MESSAGE", "MOD_QPSK", "MOD_8PSK"):
+        assert macros[name] == flat[name], name
+        assert getattr(capi, name) == flat[name], name
+        checked += 1
+    assert checked == 9
+    # the C++ host mirror spells the enumerations out: parse them the same way
+    host = open(os.path.join(T.ROOT, "gr-dvbs2rx_amd", "host", "dvbs2rx_hip_blocks.h")).read()
+    for m in re.finditer(r"enum\s+(\w+)\s*\{([^}]*)\}", host):
+        val = -1
+        for item in [x.strip() for x in m.group(2).split(",") if x.strip()]:
+            if "=" in item:
+                k, v = [y.strip() for y in item.split("=")]
+                val = int(v, 0)
+            else:
+                k, val = item, val + 1
+            assert gold[m.group(1)][k] == val, (m.group(1), k)
+    # rate enumerators: the name table of the library follows dvb_code_rate_t
+    for k, v in gold["dvb_code_rate_t"].items():
+        if k != "C_OTHER":
+            assert capi.lib.dvbs2_rate_from_name(k.encode()) == v, k
+
+
+BCH_GOLD = json.load(open(os.path.join(GOLD, "bch_golden.json")))
+
+
+@pytest.mark.parametrize("code", BCH_GOLD["codes"], ids=lambda c: f"n{c['n']}_t{c['t']}")
+def test_bch_oracle_vs_reference_digests(code):
+    """oracle/bch_oracle.c against digests taken from the GENUINE reference codec (tools/gen_bch_golden.py): every
+    BASELINE (n, t): 0..t errors, beyond t (-1, partial flips), parity-only, garbage, and both throw sites (-2)."""
+    m, prim = T.BCH_FIELDS[code["framesize"]]
+    ob = T.OracleBch(m, prim, code["t"], code["n"])
+    assert (ob.n, ob.k) == (code["n"], code["k"])
+    seen = set()
+    for c in code["cases"]:
+        rx = T.bch_golden_input(ob, code["n"], code["k"], c)
+        assert T.sha(rx) == c["sha_in"], c["name"]
+        msg, ret = ob.decode_bytes(rx[None])
+        assert int(ret[0]) == c["ret"], c["name"]
+        assert T.sha(msg[0]) == c["sha_out"], c["name"]
+        seen.add(c["ret"])
+    assert {-2, -1, 0, 1, 2, 3, code["t"]} <= seen
+
+
+def test_bch_oracle_vs_reference_live():
+    """When oracle/_ref/libdvbs2_ref_bch.so is present (it is built in the container and travels to the GPU box): random
+    words incl. the failure region, restatement vs the genuine codec."""
+    if T.ref_bch() is None:
+        pytest.skip("oracle/_ref/libdvbs2_ref_bch.so absent (reference sources not on this box and no prebuilt copy)")
+    rng = np.random.default_rng(99)
+    for fs, n, t in ((0, 3240, 12), (1, 32400, 12), (1, 58320, 8)):
+        m, prim = T.BCH_FIELDS[fs]
+        ref, ob = T.RefBch(prim, t, n), T.OracleBch(m, prim, t, n)
+        msg = rng.integers(0, 256, (12, ob.k // 8), dtype=np.uint8)
+        cw = ref.encode(msg)
+        assert np.array_equal(cw, ob.encode_bytes(msg))
+        rx = np.stack([T.flip_bits(cw[i], rng.choice(n, [0, 1, 2, t, t + 1, 15, 20, 30, 40, 41, 42, 100][i], replace=False)) for i in range(12)])
+        want, wret = ref.decode(rx)
+        got, gret = ob.decode_bytes(rx)
+        assert wret == gret.tolist() and np.array_equal(want, got)
+        ref.close()
