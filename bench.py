@@ -5,15 +5,22 @@
   (N > 1: launched by torch.distributed.run, one rank per GPU; frames shard across ranks with no
    data-path collective -- "scaling": "weak", 4096 frames per GPU per step.)
 
-A step = one pass of the hot path over one batch of synthetic frames already resident in HBM:
-QPSK 1/2 normal FECFRAMEs (DVB_S2_TABLE_B4, N=64800), LDPC capped at 50 iterations, batch 4096 per GPU,
-reference batch grouping G=32. Default input = SURVEY 8(d) primary: never-converging int8 LLRs
-clamp(round(N(0, 8^2))) so that exactly 50 updates run for every frame.
+A step = one pass of the hot path over one batch of synthetic frames already resident in HBM. The headline `value`
+is BASELINE config 2: QPSK 1/2 normal FECFRAMEs (DVB_S2_TABLE_B4, N=64800), LDPC capped at 50 iterations, batch 4096 per
+GPU, reference batch grouping G=32, never-converging int8 LLRs clamp(round(N(0, 8^2))) so that exactly 50 updates run for
+every frame (SURVEY 8(d) primary input). The same invocation also measures the other BASELINE configs and reports them
+under "configs" (each with its own parity gate, timing and roofline object):
+  config3  8PSK 3/4 normal: soft demapper + LDPC (S2_TABLE_B7) + BCH(48600,48408,12), 4096 frames, noise-only symbols
+  config4  QPSK 1/4 short (S2_TABLE_C1), 25 iterations, 16384 frames
+  config5  9/10 normal from LLRs: LDPC (S2_TABLE_B11) + BCH(58320,58192,8), 4096 frames per GPU (32768 over 8 GPUs)
+  config5_s2x  S2X 154/180 normal from LLRs: LDPC (S2X_TABLE_B21) + BCH(55440,55248,12), 4096 frames per GPU
+config 1 (one frame through a CPU path) has no counterpart: the library has no CPU path by design.
 Prints ONE JSON line (rank 0).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -23,48 +30,74 @@ sys.path.insert(0, os.path.join(ROOT, "gr-dvbs2rx_amd", "python"))
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
 
 
-def algorithmic_bytes_per_frame(N, out_bytes, links_total, iters):
+def ldpc_bytes(N, out_bytes, links_total, iters):
     # int8 LLR in + packed bits out + one int8 message read and written per edge per update
     return N + out_bytes + iters * 2 * links_total
 
 
-def cpu_baseline(table, N, trials, budget_s=10.0):
-    """Times the CPU checker on THIS box's host cores (1 thread) on a bounded sample of the same workload.
-    kind 'reference' = the genuine reference AVX2 decoder prebuilt in oracle/_ref; 'port' = oracle/."""
+# ------------------------------------------------------------------ CPU baseline (test infrastructure: drives the CHECKER)
+def physical_cores():
+    """One logical CPU per physical core among the CPUs this process may run on."""
+    allowed = sorted(os.sched_getaffinity(0))
+    seen, pick = set(), []
+    try:
+        for c in allowed:
+            base = f"/sys/devices/system/cpu/cpu{c}/topology/"
+            key = (open(base + "physical_package_id").read().strip(), open(base + "core_id").read().strip())
+            if key not in seen:
+                seen.add(key); pick.append(c)
+    except OSError:
+        pick = allowed
+    return pick
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(table, N, trials, one_core_s=3.0, all_core_s=6.0):
+    """The genuine reference AVX2 decoder (oracle/_ref, kind 'reference') on THIS box's host cores: one worker PROCESS per
+    physical core (the reference's decoder object is a global per translation unit), all started together, a bounded wall
+    time each; plus the same worker alone on one core. Falls back to the scalar restatement (kind 'port', one thread)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import fec_testlib as T
-    ref = T.ref_ldpc()
-    frames = 0
-    t0 = time.perf_counter()
-    if ref is not None:
-        kind = "reference"
-        G = ref.ref_ldpc_init(table.encode(), 0)
-        xs = [T.llr_noise(G, N, 2000 + i) for i in range(16)]
-        frames, busy = 0, 0.0
-        while busy < budget_s:
-            for x in xs:
-                y = x.copy()
-                t1 = time.perf_counter()
-                ref.ref_ldpc_decode(T.ptr(y), trials)
-                busy += time.perf_counter() - t1
-                frames += G
-        dt = busy
-        sample = (f"{frames} frames = {frames // G} AVX2 batches of {G} (16 distinct noise-LLR batches, repeated), "
-                  f"{trials} iterations, decode only, {busy:.1f} s of CPU time")
-    else:
-        kind = "port"
-        G = 32
-        x = T.llr_noise(G, N, 2000)
+    worker = os.path.join(ROOT, "tools", "cpu_ref_worker.py")
+    if T.ref_ldpc() is None:
+        x = T.llr_noise(32, N, 2000)
         t1 = time.perf_counter()
-        T.oracle_ldpc_decode(table, x, G, trials)
+        T.oracle_ldpc_decode(table, x, 32, trials)
         dt = time.perf_counter() - t1
-        frames = G
-        sample = f"{frames} frames, one scalar-port batch of {G}, noise LLRs, {trials} iterations"
-    return {"value": frames / dt, "unit": "frames/s", "cores": 1, "kind": kind, "sample": sample}
+        return {"value": 32 / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+                "sample": f"32 frames, one scalar-port batch, noise LLRs, {trials} iterations"}
+
+    def run(cpus, seconds):
+        start = time.time() + 1.5 + 0.01 * len(cpus)  # python + numpy start-up of the workers
+        procs = [subprocess.Popen([sys.executable, worker, table, str(trials), str(seconds), str(c), repr(start), str(N)],
+                                  stdout=subprocess.PIPE, text=True) for c in cpus]
+        frames, span = 0, 0.0
+        for p in procs:
+            out = p.communicate()[0].split()
+            frames += int(out[0]); span = max(span, float(out[1]))
+        return frames, span
+
+    cores = physical_cores()
+    f1, s1 = run(cores[:1], one_core_s)
+    fa, sa = run(cores, all_core_s)
+    return {"value": fa / sa, "unit": "frames/s", "cores": len(cores), "kind": "reference",
+            "sample": (f"{fa} frames in {sa:.1f} s wall: {len(cores)} processes (one per physical core, pinned) each decoding AVX2 "
+                       f"batches of 32 noise-LLR frames, {trials} iterations, decode only"),
+            "one_core": {"value": f1 / s1, "frames": f1, "seconds": s1}, "cpu_model": cpu_model(),
+            "logical_cpus": len(os.sched_getaffinity(0))}
 
 
 def measured_traffic(kernel, frames, trials):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/*.json),
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/traffic.json),
     when the profiled configuration equals the one being run; None otherwise."""
     try:
         t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
@@ -76,50 +109,73 @@ def measured_traffic(kernel, frames, trials):
     return None
 
 
-def bench_chain(args, world, rank, local, dev):
-    """BASELINE config[2]: 8PSK 3/4 normal, demap + LDPC + BCH, symbols resident in HBM (noise-only symbols:
-    worst case, every frame runs the full iteration cap and the BCH decoder sees LDPC-failed frames)."""
-    import torch
-    from dvbs2rx_amd import FecChain, capi, get_fec_info, shard
-    nf = args.frames
-    chain = FecChain(rate="C3_4", constellation=capi.MOD_8PSK, group_size=args.group, max_frames=nf,
-                     max_trials=args.trials, device=local)
-    g = torch.Generator(device=dev); g.manual_seed(777 + rank)
-    syms = torch.randn((nf, chain.n_syms * 2), generator=g, device=dev) * 0.7071
-    n0 = torch.tensor([1.0], dtype=torch.float32, device=dev)
-    msg = torch.empty((nf, chain.msg_bytes), dtype=torch.uint8, device=dev)
-    ret = torch.empty((nf + args.group - 1) // args.group, dtype=torch.int32, device=dev)
-    corr = torch.empty(nf, dtype=torch.int32, device=dev)
-    stream = torch.cuda.current_stream().cuda_stream
-
-    def step():
-        chain.work_device(syms.data_ptr(), nf, n0.data_ptr(), 1, msg.data_ptr(), ret.data_ptr(), corr.data_ptr(), stream)
-
-    for _ in range(args.warmup):
+# ------------------------------------------------------------------ timing
+def timed(step, steps, warmup, shard, dev):
+    """W untimed steps, then exactly K steps between barrier + synchronize on both sides; max over ranks."""
+    for _ in range(warmup):
         step()
     shard.barrier_sync()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         step()
     shard.barrier_sync()
-    dt = shard.max_over_ranks(time.perf_counter() - t0, device=dev)
-    if rank == 0:
-        fps = world * nf * args.steps / dt
-        b_alg = 237600 + (64800 + 48600 // 8 + args.trials * 2 * 226799) + 12126
-        print(json.dumps({"metric": "FECFRAMEs/sec, 8PSK 3/4 normal demap+LDPC+BCH chain", "value": fps, "unit": "frames/s",
-                          "coded_gbps": fps * 64800 / 1e9, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                          "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-                          "vs_baseline": None, "dtype": "int8", "data": "synthetic",
-                          "config": {"workload": f"8PSK 3/4 normal (DVB_S2_TABLE_B7 + BCH(48600,48408,t=12)), {args.trials} LDPC "
-                                                 f"iterations cap, batch={nf} per GPU, noise-only symbols", "frames_per_gpu": nf},
-                          # SURVEY 8(d) config 3: demap 237 600 + LDPC (N + K/8 + I*2*LT) + BCH 12 126 bytes per frame, against
-                          # the time of the whole step (three kernels, the LDPC sweep dominates)
-                          "roofline": {"bound": "hbm", "achieved": b_alg * nf * world * args.steps / dt / world / 1e9,
-                                       "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                       "frac": b_alg * nf * args.steps / dt / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                                       "kernel": "whole chain step: demap_8psk_kernel + ldpc_layered_kernel<16> + bch_decode_kernel",
-                                       "algorithmic_bytes_per_frame": b_alg}}))
-    shard.finalize()
+    return shard.max_over_ranks(time.perf_counter() - t0, device=dev)
+
+
+def roofline(obj, b_alg_ldpc, nf, traffic=None):
+    """HIP events around the dominant kernel (the LDPC sweep) on its launch stream: algorithmic bytes of one launch / its
+    average duration."""
+    kern_ms, launches = obj.profile(False)
+    avg_s = kern_ms / max(launches, 1) * 1e-3
+    achieved = b_alg_ldpc * nf / avg_s / 1e9 if avg_s > 0 else 0.0
+    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": traffic, "kernel": obj.kernel_name, "avg_launch_ms": avg_s * 1e3, "launches": launches,
+            "algorithmic_bytes_per_frame": b_alg_ldpc}
+
+
+def noise_llr(torch, nf, N, dev, seed):
+    g = torch.Generator(device=dev); g.manual_seed(seed)
+    return torch.clamp(torch.round(torch.randn((nf, N), generator=g, device=dev) * 8.0), -128, 127).to(torch.int8)
+
+
+def ldpc_gate(T, np, torch, dec, table, llr, G, trials, stream):
+    """GPU output of the first group must equal the CPU checker bit for bit (genuine reference when present)."""
+    N = llr.shape[1]
+    d_out = torch.empty((G, N), dtype=torch.int8, device=llr.device)
+    d_b = torch.empty((G, dec.out_bytes), dtype=torch.uint8, device=llr.device)
+    d_r = torch.empty(1, dtype=torch.int32, device=llr.device)
+    dec.work_device(llr.data_ptr(), G, d_b.data_ptr(), d_out.data_ptr(), d_r.data_ptr(), stream)
+    x = llr[:G].cpu().numpy()
+    if T.ref_ldpc() is not None and G in (16, 32):
+        want, wret = T.ref_ldpc_decode(table, x, 0 if G == 32 else 2, trials); who = "reference AVX2" if G == 32 else "reference generic"
+    else:
+        want, wret = T.oracle_ldpc_decode(table, x, G, trials); who = "oracle"
+    ok = (d_r.cpu().tolist() == wret and np.array_equal(d_out.cpu().numpy(), want)
+          and np.array_equal(d_b.cpu().numpy(), T.pack_bits(want, dec.message_bits)))
+    if not ok:
+        raise RuntimeError(f"PARITY FAILURE ({table}): GPU decode differs from the CPU checker; no number reported")
+    return "bit-exact vs " + who
+
+
+def chain_gate(T, np, torch, chain, fi, llr, G, trials, stream, fs):
+    """LLR-domain chain: first group vs genuine LDPC reference + BCH restatement (pinned by the reference's digests)."""
+    nfr = G
+    d_msg = torch.empty((nfr, chain.msg_bytes), dtype=torch.uint8, device=llr.device)
+    d_r = torch.empty(1, dtype=torch.int32, device=llr.device)
+    d_c = torch.empty(nfr, dtype=torch.int32, device=llr.device)
+    chain.work_llr_device(llr.data_ptr(), nfr, d_msg.data_ptr(), d_r.data_ptr(), d_c.data_ptr(), stream)
+    x = llr[:nfr].cpu().numpy()
+    if T.ref_ldpc() is not None and G == 32:
+        dec_llr, wret = T.ref_ldpc_decode(fi["table"], x, 0, trials); who = "reference AVX2 LDPC"
+    else:
+        dec_llr, wret = T.oracle_ldpc_decode(fi["table"], x, G, trials); who = "oracle LDPC"
+    m, prim = T.BCH_FIELDS[fs]
+    want_msg, want_corr = T.OracleBch(m, prim, fi["bch_t"], fi["bch_n"]).decode_bytes(T.pack_bits(dec_llr, fi["bch_n"]))
+    ok = (d_r.cpu().tolist() == wret and d_c.cpu().numpy().tolist() == want_corr.tolist()
+          and np.array_equal(d_msg.cpu().numpy(), want_msg))
+    if not ok:
+        raise RuntimeError(f"PARITY FAILURE (chain {fi['table']}): GPU chain differs from the CPU checker")
+    return f"bit-exact vs {who} + BCH oracle"
 
 
 def main():
@@ -132,114 +188,160 @@ def main():
     ap.add_argument("--group", type=int, default=32)
     ap.add_argument("--input", choices=["noise", "awgn"], default="noise")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", choices=["ldpc", "chain"], default="ldpc",
-                    help="ldpc = BASELINE config[1] (QPSK 1/2 normal, the headline metric); chain = config[2] "
-                         "(8PSK 3/4 normal demap+LDPC+BCH), reported as an extra line for the record")
+    ap.add_argument("--no-configs", action="store_true", help="headline only (profiling runs)")
+    ap.add_argument("--only", default="", help="comma list of extra configs to run (default: all at N=1, config5 at N>1)")
     args = ap.parse_args()
 
     import numpy as np
     import torch
-    from dvbs2rx_amd import LdpcDecoder, capi, ldpc_table_info, shard
+    from dvbs2rx_amd import FecChain, LdpcDecoder, capi, get_fec_info, ldpc_table_info, shard
 
     world, rank, local = shard.init_from_env()  # nccl (= RCCL) rendezvous when WORLD_SIZE > 1
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    if local >= torch.cuda.device_count():  # more ranks than GPUs: only for exercising the N > 1 path on a small box
-        local = local % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if capi.lib.dvbs2_device_count() < 1:
         raise RuntimeError("no HIP device: the hot path has no CPU fallback")
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import fec_testlib as T  # the CPU checkers: parity gates and the cpu_baseline leg only
+    stream = torch.cuda.current_stream().cuda_stream
+    G = args.group
 
-    if args.workload == "chain":
-        return bench_chain(args, world, rank, local, dev)
+    # ---------------------------------------------------------------- headline: BASELINE config 2
     table = "S2_TABLE_B4"
     info = ldpc_table_info(table)
     N, K = info["N"], info["K"]
     nf = args.frames
     dec = LdpcDecoder(standard=capi.STANDARD_DVBS2, framesize=capi.FECFRAME_NORMAL, rate="C1_2",
-                      outputmode=capi.OM_MESSAGE, max_trials=args.trials, group_size=args.group,
-                      max_frames=nf, device=local)
+                      outputmode=capi.OM_MESSAGE, max_trials=args.trials, group_size=G, max_frames=nf, device=local)
     out_bytes = dec.out_bytes
-
-    # synthetic input generated on the device (independent per rank)
-    g = torch.Generator(device=dev); g.manual_seed(12345 + rank)
     if args.input == "noise":
-        llr = torch.clamp(torch.round(torch.randn((nf, N), generator=g, device=dev) * 8.0), -128, 127).to(torch.int8)
+        llr = noise_llr(torch, nf, N, dev, 12345 + rank)
     else:
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
-        import fec_testlib as T
         base, _ = T.llr_codeword_awgn(table, 64, 4242 + rank, amp=6, sigma=5.2)
         llr = torch.from_numpy(np.tile(base, (nf // 64 + 1, 1))[:nf]).to(dev)
     d_bits = torch.empty((nf, out_bytes), dtype=torch.uint8, device=dev)
-    d_ret = torch.empty((nf + args.group - 1) // args.group, dtype=torch.int32, device=dev)
-    stream = torch.cuda.current_stream().cuda_stream
+    d_ret = torch.empty((nf + G - 1) // G, dtype=torch.int32, device=dev)
+    parity = ldpc_gate(T, np, torch, dec, table, llr, G, args.trials, stream) if rank == 0 else "skipped"
 
     def step():
         dec.work_device(llr.data_ptr(), nf, d_bits.data_ptr(), 0, d_ret.data_ptr(), stream)
 
-    barrier = shard.barrier_sync
-
-    # parity gate on the first group (rank 0): GPU output must equal the CPU checker bit for bit
-    parity = "skipped"
-    if rank == 0:
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
-        import fec_testlib as T
-        G = args.group
-        d_llr_out = torch.empty((G, N), dtype=torch.int8, device=dev)
-        d_b = torch.empty((G, out_bytes), dtype=torch.uint8, device=dev)
-        d_r = torch.empty(1, dtype=torch.int32, device=dev)
-        dec.work_device(llr.data_ptr(), G, d_b.data_ptr(), d_llr_out.data_ptr(), d_r.data_ptr(), stream)
-        x = llr[:G].cpu().numpy()
-        if T.ref_ldpc() is not None and G in (16, 32):
-            want, wret = T.ref_ldpc_decode(table, x, 0 if G == 32 else 2, args.trials)
-        else:
-            want, wret = T.oracle_ldpc_decode(table, x, G, args.trials)
-        ok = (d_r.cpu().tolist() == wret and np.array_equal(d_llr_out.cpu().numpy(), want)
-              and np.array_equal(d_b.cpu().numpy(), T.pack_bits(want, dec.message_bits)))
-        if not ok:
-            raise RuntimeError("PARITY FAILURE: GPU decode differs from the CPU checker; no number reported")
-        parity = "bit-exact vs " + ("reference AVX2" if T.ref_ldpc() is not None and G == 32 else "oracle")
-
     for _ in range(args.warmup):
         step()
     dec.profile(True)  # HIP events around the dominant kernel, on its launch stream
-    kname = dec.kernel_name
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    dt = time.perf_counter() - t0
-    kern_ms, launches = dec.profile(False)
+    dt = timed(step, args.steps, 0, shard, dev)
     iters_mean = float((args.trials - d_ret.clamp(min=0)).float().mean().item()) if args.input != "noise" else float(args.trials)
+    b_alg = ldpc_bytes(N, out_bytes, info["links_total"], args.trials if args.input == "noise" else iters_mean)
+    rl = roofline(dec, b_alg, nf, measured_traffic(dec.kernel_name, nf, args.trials) if args.input == "noise" else None)
+    rl["limiter"] = "VALU pipe (half-rate min/med3/sad/add3), not HBM: DESIGN.md 3.3"
+    fps = world * nf * args.steps / dt
+    out = {
+        "metric": "FECFRAMEs/sec (coded Gbit/s) @ 50 LDPC iters, QPSK 1/2 normal",
+        "value": fps, "unit": "frames/s", "coded_gbps": fps * N / 1e9,
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "int8", "data": "synthetic",
+        "config": {"workload": f"QPSK 1/2 normal FECFRAME (DVB_S2_TABLE_B4, N=64800), {args.trials} LDPC iterations cap, "
+                               f"batch={nf} frames per GPU, group G={G}, input={args.input}",
+                   "frames_per_gpu": nf, "max_trials": args.trials, "group_size": G,
+                   "mean_iterations": iters_mean, "parallelism": f"frames sharded over {world} GPU(s), no collective"},
+        "parity": parity, "roofline": rl,
+    }
+    dec.close()
+    del llr, d_bits
 
-    dt = shard.max_over_ranks(dt, device=dev)
+    # ---------------------------------------------------------------- the other BASELINE configs, same clock discipline
+    steps2 = max(2, min(args.steps, 3))
+    want = [c for c in args.only.split(",") if c] or (["config3", "config4", "config5", "config5_s2x"] if world == 1 else ["config5"])
+    configs = {}
+
+    def ldpc_only(name, tbl, frames, trials, label):
+        ti = ldpc_table_info(tbl)
+        d = LdpcDecoder(table=tbl, message_bits=ti["K"], outputmode=capi.OM_MESSAGE, max_trials=trials, group_size=G,
+                        max_frames=frames, device=local)
+        x = noise_llr(torch, frames, ti["N"], dev, 777 + rank)
+        b = torch.empty((frames, d.out_bytes), dtype=torch.uint8, device=dev)
+        r = torch.empty((frames + G - 1) // G, dtype=torch.int32, device=dev)
+        par = ldpc_gate(T, np, torch, d, tbl, x, G, trials, stream) if rank == 0 else "skipped"
+        fn = lambda: d.work_device(x.data_ptr(), frames, b.data_ptr(), 0, r.data_ptr(), stream)
+        fn(); d.profile(True)
+        t = timed(fn, steps2, 0, shard, dev)
+        bl = ldpc_bytes(ti["N"], d.out_bytes, ti["links_total"], trials)
+        configs[name] = {"workload": label, "value": world * frames * steps2 / t, "unit": "frames/s",
+                         "coded_gbps": world * frames * steps2 / t * ti["N"] / 1e9, "frames_per_gpu": frames, "max_trials": trials,
+                         "steps": steps2, "ms_per_step": t / steps2 * 1e3, "parity": par, "roofline": roofline(d, bl, frames)}
+        d.close()
+
+    def llr_chain(name, rate, frames, trials, label):
+        fi = get_fec_info(capi.STANDARD_DVBS2, capi.FECFRAME_NORMAL, rate)
+        ti = ldpc_table_info(fi["table"])
+        ch = FecChain(rate=rate, group_size=G, max_frames=frames, max_trials=trials, device=local, from_llr=True)
+        x = noise_llr(torch, frames, ti["N"], dev, 888 + rank)
+        m = torch.empty((frames, ch.msg_bytes), dtype=torch.uint8, device=dev)
+        r = torch.empty((frames + G - 1) // G, dtype=torch.int32, device=dev)
+        c = torch.empty(frames, dtype=torch.int32, device=dev)
+        par = chain_gate(T, np, torch, ch, fi, x, G, trials, stream, capi.FECFRAME_NORMAL) if rank == 0 else "skipped"
+        fn = lambda: ch.work_llr_device(x.data_ptr(), frames, m.data_ptr(), r.data_ptr(), c.data_ptr(), stream)
+        fn(); ch.profile(True)
+        t = timed(fn, steps2, 0, shard, dev)
+        bl = ldpc_bytes(ti["N"], fi["bch_n"] // 8, ti["links_total"], trials)
+        b_step = bl + fi["bch_n"] // 8 + fi["bch_k"] // 8
+        val = world * frames * steps2 / t
+        configs[name] = {"workload": label, "value": val, "unit": "frames/s", "coded_gbps": val * ti["N"] / 1e9,
+                         "frames_per_gpu": frames, "frames_total": world * frames, "max_trials": trials, "steps": steps2,
+                         "ms_per_step": t / steps2 * 1e3, "parity": par, "roofline": roofline(ch, bl, frames),
+                         "step_bytes_per_frame": b_step, "step_frac_of_hbm_peak": b_step * val / world / 1e9 / HBM_PEAK_GBS}
+        ch.close()
+
+    if not args.no_configs:
+        if "config3" in want:
+            fi = get_fec_info(capi.STANDARD_DVBS2, capi.FECFRAME_NORMAL, "C3_4")
+            ch = FecChain(rate="C3_4", constellation=capi.MOD_8PSK, group_size=G, max_frames=nf, max_trials=args.trials, device=local)
+            g = torch.Generator(device=dev); g.manual_seed(777 + rank)
+            syms = torch.randn((nf, ch.n_syms * 2), generator=g, device=dev) * 0.7071
+            n0 = torch.tensor([1.0], dtype=torch.float32, device=dev)
+            msg = torch.empty((nf, ch.msg_bytes), dtype=torch.uint8, device=dev)
+            r = torch.empty((nf + G - 1) // G, dtype=torch.int32, device=dev)
+            c = torch.empty(nf, dtype=torch.int32, device=dev)
+            fn = lambda: ch.work_device(syms.data_ptr(), nf, n0.data_ptr(), 1, msg.data_ptr(), r.data_ptr(), c.data_ptr(), stream)
+            par = "skipped"
+            if rank == 0:  # first group through the CPU checkers: demapper restatement -> genuine LDPC -> BCH restatement
+                fn()
+                rx = syms[:G].cpu().numpy().view(np.complex64)
+                x = T.oracle_demap(rx, np.float32(1.0), 8, 0)
+                dl, wret = (T.ref_ldpc_decode(fi["table"], x, 0, args.trials) if T.ref_ldpc() is not None and G == 32
+                            else T.oracle_ldpc_decode(fi["table"], x, G, args.trials))
+                m_, prim = T.BCH_FIELDS[capi.FECFRAME_NORMAL]
+                wm, wc = T.OracleBch(m_, prim, fi["bch_t"], fi["bch_n"]).decode_bytes(T.pack_bits(dl, fi["bch_n"]))
+                if not (r[:1].cpu().tolist() == wret and c[:G].cpu().numpy().tolist() == wc.tolist() and np.array_equal(msg[:G].cpu().numpy(), wm)):
+                    raise RuntimeError("PARITY FAILURE (config3 chain)")
+                par = "bit-exact vs demapper oracle (parity unpinned) + reference AVX2 LDPC + BCH oracle"
+            fn(); ch.profile(True)
+            t = timed(fn, steps2, 0, shard, dev)
+            ti = ldpc_table_info(fi["table"])
+            bl = ldpc_bytes(64800, fi["bch_n"] // 8, ti["links_total"], args.trials)
+            b_step = 8 * 21600 + 64800 + bl + fi["bch_n"] // 8 + fi["bch_k"] // 8
+            val = world * nf * steps2 / t
+            configs["config3"] = {"workload": f"8PSK 3/4 normal: demapper + LDPC (S2_TABLE_B7) + BCH(48600,48408,12), {args.trials} iterations cap, "
+                                              f"batch={nf}, noise-only symbols (every frame runs the cap; BCH sees failed frames)",
+                                  "value": val, "unit": "frames/s", "coded_gbps": val * 64800 / 1e9, "frames_per_gpu": nf,
+                                  "max_trials": args.trials, "steps": steps2, "ms_per_step": t / steps2 * 1e3, "parity": par,
+                                  "roofline": roofline(ch, bl, nf), "step_bytes_per_frame": b_step,
+                                  "step_frac_of_hbm_peak": b_step * val / world / 1e9 / HBM_PEAK_GBS}
+            ch.close(); del syms
+        if "config4" in want:
+            ldpc_only("config4", "S2_TABLE_C1", 16384, 25, "QPSK 1/4 short (S2_TABLE_C1, N=16200), 25 iterations cap, batch=16384, noise LLRs")
+        if "config5" in want:
+            llr_chain("config5", "C9_10", nf, args.trials,
+                      f"9/10 normal from LLRs: LDPC (S2_TABLE_B11) + BCH(58320,58192,8), {args.trials} iterations cap, {nf} frames per GPU "
+                      f"x {world} GPU(s) (BASELINE: 32768 over 8; the reference has no 32APSK demapper), noise LLRs")
+        if "config5_s2x" in want:
+            llr_chain("config5_s2x", "C154_180", nf, args.trials,
+                      f"S2X 154/180 normal from LLRs: LDPC (S2X_TABLE_B21) + BCH(55440,55248,12), {args.trials} iterations cap, {nf} frames per GPU, noise LLRs")
+        out["configs"] = configs
 
     if rank == 0:
-        frames_total = world * nf * args.steps
-        fps = frames_total / dt
-        b_alg = algorithmic_bytes_per_frame(N, out_bytes, info["links_total"], args.trials if args.input == "noise" else iters_mean)
-        avg_kernel_s = (kern_ms / max(launches, 1)) * 1e-3
-        # HIP-event timing serialises the step (event sync per launch); whole-job time above includes it
-        achieved = b_alg * nf / avg_kernel_s / 1e9 if avg_kernel_s > 0 else 0.0
-        out = {
-            "metric": "FECFRAMEs/sec (coded Gbit/s) @ 50 LDPC iters, QPSK 1/2 normal",
-            "value": fps, "unit": "frames/s", "coded_gbps": fps * N / 1e9,
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "int8", "data": "synthetic",
-            "config": {"workload": f"QPSK 1/2 normal FECFRAME (DVB_S2_TABLE_B4, N=64800), {args.trials} LDPC iterations cap, "
-                                   f"batch={nf} frames per GPU, group G={args.group}, input={args.input}",
-                       "frames_per_gpu": nf, "max_trials": args.trials, "group_size": args.group,
-                       "mean_iterations": iters_mean, "parallelism": f"frames sharded over {world} GPU(s), no collective"},
-            "parity": parity,
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": measured_traffic(kname, nf, args.trials) if args.input == "noise" else None,
-                         "kernel": kname, "avg_launch_ms": avg_kernel_s * 1e3, "launches": launches,
-                         "algorithmic_bytes_per_frame": b_alg,
-                         "limiter": "VALU pipe (half-rate min/med3/sad/add3), not HBM: DESIGN.md 3.3"},
-        }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(table, N, args.trials)
         print(json.dumps(out))

@@ -10,6 +10,8 @@
 #include "bch_hip.h"
 #include "demap_hip.h"
 #include "plpayload_hip.h"
+#include "device_guard.h"
+#include <algorithm>
 
 using namespace dvbs2;
 
@@ -22,9 +24,13 @@ static int fail(int code, const std::string& msg) { g_err = msg; return code; }
 
 struct dvbs2_ldpc {
     LdpcDecoderHip* dec = nullptr;
-    // host staging
+    // host staging (dvbs2_ldpc_decode): device copies of the caller's buffers and two streams, so that the transfer of
+    // chunk c + 1 runs under the decode of chunk c
     int8_t* d_in = nullptr; uint8_t* d_bits = nullptr; int8_t* d_llr = nullptr; int32_t* d_ret = nullptr;
-    hipStream_t stream = nullptr;
+    // pinned landing buffers for the outputs: a device-to-host copy into pageable memory blocks the calling thread until
+    // the chunk's kernels are done, which would serialise the chunks
+    uint8_t* p_bits = nullptr; int8_t* p_llr = nullptr; int32_t* p_ret = nullptr;
+    hipStream_t stream[LdpcDecoderHip::kSlots] = {};
     int device = 0;
 };
 
@@ -37,6 +43,20 @@ int dvbs2_device_count(void)
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
     return n;
+}
+
+int dvbs2_host_register(void* p, size_t bytes)
+{
+    if (!p || !bytes) return fail(DVBS2_EINVAL, "bad argument");
+    HCHK(hipHostRegister(p, bytes, hipHostRegisterDefault));
+    return DVBS2_OK;
+}
+
+int dvbs2_host_unregister(void* p)
+{
+    if (!p) return fail(DVBS2_EINVAL, "bad argument");
+    HCHK(hipHostUnregister(p));
+    return DVBS2_OK;
 }
 
 int dvbs2_get_fec_info(int standard, int framesize, int rate, dvbs2_fec_info_t* out)
@@ -134,9 +154,12 @@ int dvbs2_ldpc_create_table(dvbs2_ldpc_t** h, const char* table, int message_bit
 void dvbs2_ldpc_destroy(dvbs2_ldpc_t* h)
 {
     if (!h) return;
-    (void)hipSetDevice(h->device);
+    DeviceGuard g(h->device);
     (void)hipFree(h->d_in); (void)hipFree(h->d_bits); (void)hipFree(h->d_llr); (void)hipFree(h->d_ret);
-    if (h->stream) (void)hipStreamDestroy(h->stream);
+    if (h->p_bits) (void)hipHostFree(h->p_bits);
+    if (h->p_llr) (void)hipHostFree(h->p_llr);
+    if (h->p_ret) (void)hipHostFree(h->p_ret);
+    for (hipStream_t st : h->stream) if (st) (void)hipStreamDestroy(st);
     delete h->dec;
     delete h;
 }
@@ -150,16 +173,42 @@ int dvbs2_ldpc_params(const dvbs2_ldpc_t* h, int* n, int* table_k, int* message_
     return DVBS2_OK;
 }
 
+static int ldpc_check_args(dvbs2_ldpc_t* h, const void* in, int n_frames, int max_trials, int out_mode, const void* bits)
+{
+    if (!h) return fail(DVBS2_EINVAL, "null handle");
+    if (n_frames < 0 || max_trials <= 0 || (n_frames && (!in || !bits))) return fail(DVBS2_EINVAL, "bad argument");
+    if (out_mode != DVBS2_OM_CODEWORD && out_mode != DVBS2_OM_MESSAGE) return fail(DVBS2_EINVAL, "bad out_mode");
+    if (n_frames > h->dec->max_frames()) return fail(DVBS2_ESIZE, "n_frames exceeds max_frames");
+    return DVBS2_OK;
+}
+
 int dvbs2_ldpc_decode_device(dvbs2_ldpc_t* h, const int8_t* d_llr_in, int n_frames, int max_trials, int out_mode,
                              uint8_t* d_bits_out, int8_t* d_llr_out, int32_t* d_ret, void* stream)
 {
     API_TRY
-    if (!h) return fail(DVBS2_EINVAL, "null handle");
-    if (n_frames < 0 || max_trials <= 0 || (n_frames && (!d_llr_in || !d_bits_out))) return fail(DVBS2_EINVAL, "bad argument");
-    if (out_mode != DVBS2_OM_CODEWORD && out_mode != DVBS2_OM_MESSAGE) return fail(DVBS2_EINVAL, "bad out_mode");
-    if (n_frames > h->dec->max_frames()) return fail(DVBS2_ESIZE, "n_frames exceeds max_frames");
+    if (int rc = ldpc_check_args(h, d_llr_in, n_frames, max_trials, out_mode, d_bits_out)) return rc;
     if (h->dec->decode_device(d_llr_in, n_frames, max_trials, out_mode, d_bits_out, d_llr_out, d_ret, (hipStream_t)stream))
         return fail(DVBS2_EDEVICE, h->dec->error());
+    return DVBS2_OK;
+    API_CATCH
+}
+
+int dvbs2_ldpc_enqueue_device(dvbs2_ldpc_t* h, const int8_t* d_llr_in, int n_frames, int max_trials, int out_mode,
+                              uint8_t* d_bits_out, int8_t* d_llr_out, int32_t* d_ret, void* stream)
+{
+    API_TRY
+    if (int rc = ldpc_check_args(h, d_llr_in, n_frames, max_trials, out_mode, d_bits_out)) return rc;
+    if (h->dec->enqueue(d_llr_in, n_frames, max_trials, out_mode, d_bits_out, d_llr_out, d_ret, (hipStream_t)stream, 0, 0))
+        return fail(DVBS2_EDEVICE, h->dec->error());
+    return DVBS2_OK;
+    API_CATCH
+}
+
+int dvbs2_ldpc_finish(dvbs2_ldpc_t* h)
+{
+    API_TRY
+    if (!h) return fail(DVBS2_EINVAL, "null handle");
+    if (h->dec->finish(0) < 0) return fail(DVBS2_EDEVICE, h->dec->error());
     return DVBS2_OK;
     API_CATCH
 }
@@ -168,27 +217,60 @@ int dvbs2_ldpc_decode(dvbs2_ldpc_t* h, const int8_t* llr_in, int n_frames, int m
                       uint8_t* bits_out, int8_t* llr_out, int32_t* ret)
 {
     API_TRY
-    if (!h) return fail(DVBS2_EINVAL, "null handle");
-    if (n_frames < 0 || max_trials <= 0 || (n_frames && (!llr_in || !bits_out))) return fail(DVBS2_EINVAL, "bad argument");
-    if (out_mode != DVBS2_OM_CODEWORD && out_mode != DVBS2_OM_MESSAGE) return fail(DVBS2_EINVAL, "bad out_mode");
-    if (n_frames > h->dec->max_frames()) return fail(DVBS2_ESIZE, "n_frames exceeds max_frames");
+    if (int rc = ldpc_check_args(h, llr_in, n_frames, max_trials, out_mode, bits_out)) return rc;
     if (n_frames == 0) return DVBS2_OK;
-    HCHK(hipSetDevice(h->device));
+    DeviceGuard guard(h->device);
+    if (!guard.ok) return fail(DVBS2_EDEVICE, "hipSetDevice failed");
     const size_t N = h->dec->N(), mf = h->dec->max_frames();
     const int G = h->dec->group_size();
-    if (!h->stream) HCHK(hipStreamCreate(&h->stream));
+    for (hipStream_t& st : h->stream) if (!st) HCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
     if (!h->d_in) HCHK(hipMalloc(&h->d_in, mf * N));
     if (!h->d_bits) HCHK(hipMalloc(&h->d_bits, mf * (N / 8)));
     if (!h->d_llr) HCHK(hipMalloc(&h->d_llr, mf * N));
-    if (!h->d_ret) HCHK(hipMalloc(&h->d_ret, ((mf + G - 1) / G) * 4));
+    if (!h->d_ret) HCHK(hipMalloc(&h->d_ret, ((mf + G - 1) / G + LdpcDecoderHip::kSlots) * 4));
+    if (!h->p_bits) HCHK(hipHostMalloc(&h->p_bits, mf * (N / 8)));
+    if (!h->p_ret) HCHK(hipHostMalloc(&h->p_ret, ((mf + G - 1) / G + LdpcDecoderHip::kSlots) * 4));
+    if (llr_out && !h->p_llr) HCHK(hipHostMalloc(&h->p_llr, mf * N));
     const size_t out_bytes = (out_mode ? h->dec->out_bits_message() : (int)N) / 8;
-    HCHK(hipMemcpyAsync(h->d_in, llr_in, (size_t)n_frames * N, hipMemcpyHostToDevice, h->stream));
-    if (h->dec->decode_device(h->d_in, n_frames, max_trials, out_mode, h->d_bits, llr_out ? h->d_llr : nullptr, h->d_ret, h->stream))
-        return fail(DVBS2_EDEVICE, h->dec->error());
-    HCHK(hipMemcpyAsync(bits_out, h->d_bits, (size_t)n_frames * out_bytes, hipMemcpyDeviceToHost, h->stream));
-    if (llr_out) HCHK(hipMemcpyAsync(llr_out, h->d_llr, (size_t)n_frames * N, hipMemcpyDeviceToHost, h->stream));
-    if (ret) HCHK(hipMemcpyAsync(ret, h->d_ret, (size_t)((n_frames + G - 1) / G) * 4, hipMemcpyDeviceToHost, h->stream));
-    HCHK(hipStreamSynchronize(h->stream));
+    // Chunks of whole groups (an even number of frames: two frames per workgroup) of at least 512 frames -- one frame pair
+    // per CU; a smaller launch takes just as long -- and about an eighth of the call: the host-to-device copy of chunk
+    // c + 1 and the device-to-host copies of chunk c - 1 run under the decode of chunk c. Chunk c uses slot and stream
+    // c % kSlots (its own range of the state and message buffers).
+    int unit = G % 2 ? 2 * G : G;
+    int chunk = std::max(512, (n_frames + 7) / 8);
+    if (const char* e = getenv("DVBS2_HOST_CHUNK")) chunk = std::max(2, atoi(e)); // experiments
+    chunk = (chunk + unit - 1) / unit * unit;
+    const int n_chunks = (n_frames + chunk - 1) / chunk;
+    auto copy_out = [&](int c) -> int {
+        const int f0 = c * chunk, nf = std::min(chunk, n_frames - f0);
+        hipStream_t st = h->stream[c % LdpcDecoderHip::kSlots];
+        HCHK(hipMemcpyAsync(h->p_bits + (size_t)f0 * out_bytes, h->d_bits + (size_t)f0 * out_bytes, (size_t)nf * out_bytes, hipMemcpyDeviceToHost, st));
+        if (llr_out) HCHK(hipMemcpyAsync(h->p_llr + (size_t)f0 * N, h->d_llr + (size_t)f0 * N, (size_t)nf * N, hipMemcpyDeviceToHost, st));
+        if (ret) HCHK(hipMemcpyAsync(h->p_ret + f0 / G, h->d_ret + f0 / G, (size_t)((nf + G - 1) / G) * 4, hipMemcpyDeviceToHost, st));
+        return DVBS2_OK;
+    };
+    auto finish = [&](int c) -> int {
+        const int r = h->dec->finish(c % LdpcDecoderHip::kSlots);
+        if (r < 0) return fail(DVBS2_EDEVICE, h->dec->error());
+        if (r > 0) { if (int rc = copy_out(c)) return rc; } // outputs rewritten by the extra rounds: fetch them again
+        HCHK(hipStreamSynchronize(h->stream[c % LdpcDecoderHip::kSlots]));
+        const int f0 = c * chunk, nf = std::min(chunk, n_frames - f0);
+        std::memcpy(bits_out + (size_t)f0 * out_bytes, h->p_bits + (size_t)f0 * out_bytes, (size_t)nf * out_bytes);
+        if (llr_out) std::memcpy(llr_out + (size_t)f0 * N, h->p_llr + (size_t)f0 * N, (size_t)nf * N);
+        if (ret) std::memcpy(ret + f0 / G, h->p_ret + f0 / G, (size_t)((nf + G - 1) / G) * 4);
+        return DVBS2_OK;
+    };
+    for (int c = 0; c < n_chunks; c++) {
+        if (c >= LdpcDecoderHip::kSlots) if (int rc = finish(c - LdpcDecoderHip::kSlots)) return rc;
+        const int f0 = c * chunk, nf = std::min(chunk, n_frames - f0);
+        hipStream_t st = h->stream[c % LdpcDecoderHip::kSlots];
+        HCHK(hipMemcpyAsync(h->d_in + (size_t)f0 * N, llr_in + (size_t)f0 * N, (size_t)nf * N, hipMemcpyHostToDevice, st));
+        if (h->dec->enqueue(h->d_in + (size_t)f0 * N, nf, max_trials, out_mode, h->d_bits + (size_t)f0 * out_bytes,
+                            llr_out ? h->d_llr + (size_t)f0 * N : nullptr, h->d_ret + f0 / G, st, c % LdpcDecoderHip::kSlots, f0))
+            return fail(DVBS2_EDEVICE, h->dec->error());
+        if (int rc = copy_out(c)) return rc;
+    }
+    for (int c = std::max(0, n_chunks - LdpcDecoderHip::kSlots); c < n_chunks; c++) if (int rc = finish(c)) return rc;
     return DVBS2_OK;
     API_CATCH
 }
@@ -276,7 +358,7 @@ int dvbs2_bch_create_raw(dvbs2_bch_t** h, int m, uint32_t prim_poly, int t, int 
 void dvbs2_bch_destroy(dvbs2_bch_t* h)
 {
     if (!h) return;
-    (void)hipSetDevice(h->device);
+    DeviceGuard guard(h->device);
     (void)hipFree(h->d_cw); (void)hipFree(h->d_msg); (void)hipFree(h->d_corr);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h->dec;
@@ -332,7 +414,8 @@ int dvbs2_bch_decode(dvbs2_bch_t* h, const uint8_t* cw, int n_frames, uint8_t* m
     if (n_frames < 0 || (n_frames && (!cw || !msg || !corrections))) return fail(DVBS2_EINVAL, "bad argument");
     if (n_frames > h->dec->max_frames()) return fail(DVBS2_ESIZE, "n_frames exceeds max_frames");
     if (n_frames == 0) return DVBS2_OK;
-    HCHK(hipSetDevice(h->device));
+    DeviceGuard guard(h->device);
+    if (!guard.ok) return fail(DVBS2_EDEVICE, "hipSetDevice failed");
     const size_t nb = h->dec->code().n / 8, kb = h->dec->code().k / 8, mf = h->dec->max_frames();
     if (!h->stream) HCHK(hipStreamCreate(&h->stream));
     if (!h->d_cw) HCHK(hipMalloc(&h->d_cw, mf * nb));
@@ -378,7 +461,7 @@ int dvbs2_demap_create(dvbs2_demap_t** h, int framesize, int rate, int constella
 void dvbs2_demap_destroy(dvbs2_demap_t* h)
 {
     if (!h) return;
-    (void)hipSetDevice(h->device);
+    DeviceGuard guard(h->device);
     (void)hipFree(h->d_syms); (void)hipFree(h->d_n0); (void)hipFree(h->d_llr); (void)hipFree(h->d_snr);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h->dm;
@@ -406,7 +489,8 @@ int dvbs2_demap_soft_device(dvbs2_demap_t* h, const float* d_syms, int n_frames,
 
 static int demap_stage(dvbs2_demap_t* h, const float* syms, int n_frames)
 {
-    HCHK(hipSetDevice(h->device));
+    DeviceGuard guard(h->device);
+    if (!guard.ok) return fail(DVBS2_EDEVICE, "hipSetDevice failed");
     const size_t mf = h->dm->max_frames(), ns = h->dm->n_syms();
     if (!h->stream) HCHK(hipStreamCreate(&h->stream));
     if (!h->d_syms) HCHK(hipMalloc(&h->d_syms, mf * ns * 8));
@@ -490,10 +574,50 @@ int dvbs2_demap_refine_snr(dvbs2_demap_t* h, const float* syms, const int8_t* re
 
 /* ------------------------------------------------------------------ chain */
 struct dvbs2_chain {
-    dvbs2_demap_t* dm = nullptr; dvbs2_ldpc_t* ldpc = nullptr; dvbs2_bch_t* bch = nullptr;
+    dvbs2_demap_t* dm = nullptr; // absent for an LLR-domain chain (dvbs2_chain_create_llr)
+    dvbs2_ldpc_t* ldpc = nullptr; dvbs2_bch_t* bch = nullptr;
     int8_t* d_llr = nullptr; uint8_t* d_bits = nullptr; int32_t* d_corr = nullptr;
     int device = 0, max_frames = 0, n_llr = 0, ldpc_bytes = 0, msg_bytes = 0;
+    // the call between enqueue and finish
+    bool pending = false; int n_frames = 0; uint8_t* d_msg = nullptr; int32_t* d_bch_corr = nullptr; void* stream = nullptr;
 };
+
+static int chain_make(dvbs2_chain_t** h, int standard, int framesize, int rate, int constellation, bool with_demap,
+                      int group_size, int max_frames, int device)
+{
+    if (!h) return fail(DVBS2_EINVAL, "null handle pointer");
+    *h = nullptr;
+    dvbs2_chain* o = new (std::nothrow) dvbs2_chain();
+    if (!o) return fail(DVBS2_EDEVICE, "out of memory");
+    o->device = device; o->max_frames = max_frames;
+    int rc = DVBS2_OK;
+    if (with_demap) rc = dvbs2_demap_create(&o->dm, framesize, rate, constellation, max_frames, device);
+    if (rc == DVBS2_OK) rc = dvbs2_ldpc_create(&o->ldpc, standard, framesize, rate, group_size, max_frames, device);
+    if (rc == DVBS2_OK) rc = dvbs2_bch_create(&o->bch, standard, framesize, rate, max_frames, device);
+    if (rc != DVBS2_OK) { std::string keep = g_err; dvbs2_chain_destroy(o); return fail(rc, keep); }
+    o->n_llr = o->ldpc->dec->N();
+    o->ldpc_bytes = o->ldpc->dec->out_bits_message() / 8;
+    o->msg_bytes = o->bch->dec->code().k / 8;
+    if ((o->dm && o->dm->dm->n_llr() != o->n_llr) || o->ldpc_bytes != o->bch->dec->code().n / 8) { dvbs2_chain_destroy(o); return fail(DVBS2_EINVAL, "inconsistent chain sizes"); }
+    DeviceGuard guard(device);
+    hipError_t e = guard.ok ? hipSuccess : hipErrorInvalidDevice;
+    if (e == hipSuccess && o->dm) e = hipMalloc(&o->d_llr, (size_t)max_frames * o->n_llr);
+    if (e == hipSuccess) e = hipMalloc(&o->d_bits, (size_t)max_frames * o->ldpc_bytes);
+    if (e == hipSuccess) e = hipMalloc(&o->d_corr, (size_t)max_frames * 4);
+    if (e != hipSuccess) { dvbs2_chain_destroy(o); return fail(DVBS2_EDEVICE, hipGetErrorString(e)); }
+    *h = o;
+    return DVBS2_OK;
+}
+
+// LDPC (already enqueued) -> BCH on the same stream; the LDPC output never leaves HBM
+static int chain_enqueue_tail(dvbs2_chain_t* h, const int8_t* d_llr, int n_frames, int max_trials, uint8_t* d_msg,
+                              int32_t* d_ldpc_ret, int32_t* d_bch_corr, void* stream)
+{
+    if (h->ldpc->dec->enqueue(d_llr, n_frames, max_trials, DVBS2_OM_MESSAGE, h->d_bits, nullptr, d_ldpc_ret, (hipStream_t)stream, 0, 0))
+        return fail(DVBS2_EDEVICE, h->ldpc->dec->error());
+    h->pending = true; h->n_frames = n_frames; h->d_msg = d_msg; h->d_bch_corr = d_bch_corr ? d_bch_corr : h->d_corr; h->stream = stream;
+    return dvbs2_bch_decode_device(h->bch, h->d_bits, n_frames, d_msg, h->d_bch_corr, stream);
+}
 
 extern "C" {
 
@@ -506,7 +630,7 @@ int dvbs2_chain_set_descramble(dvbs2_chain_t* h, int enable)
 void dvbs2_chain_destroy(dvbs2_chain_t* h)
 {
     if (!h) return;
-    (void)hipSetDevice(h->device);
+    DeviceGuard guard(h->device);
     dvbs2_demap_destroy(h->dm); dvbs2_ldpc_destroy(h->ldpc); dvbs2_bch_destroy(h->bch);
     (void)hipFree(h->d_llr); (void)hipFree(h->d_bits); (void)hipFree(h->d_corr);
     delete h;
@@ -515,48 +639,102 @@ void dvbs2_chain_destroy(dvbs2_chain_t* h)
 int dvbs2_chain_create(dvbs2_chain_t** h, int standard, int framesize, int rate, int constellation, int group_size, int max_frames, int device)
 {
     API_TRY
-    if (!h) return fail(DVBS2_EINVAL, "null handle pointer");
-    *h = nullptr;
-    dvbs2_chain* o = new (std::nothrow) dvbs2_chain();
-    if (!o) return fail(DVBS2_EDEVICE, "out of memory");
-    o->device = device; o->max_frames = max_frames;
-    int rc = dvbs2_demap_create(&o->dm, framesize, rate, constellation, max_frames, device);
-    if (rc == DVBS2_OK) rc = dvbs2_ldpc_create(&o->ldpc, standard, framesize, rate, group_size, max_frames, device);
-    if (rc == DVBS2_OK) rc = dvbs2_bch_create(&o->bch, standard, framesize, rate, max_frames, device);
-    if (rc != DVBS2_OK) { std::string keep = g_err; dvbs2_chain_destroy(o); return fail(rc, keep); }
-    o->n_llr = o->dm->dm->n_llr();
-    o->ldpc_bytes = o->ldpc->dec->out_bits_message() / 8;
-    o->msg_bytes = o->bch->dec->code().k / 8;
-    if (o->ldpc->dec->N() != o->n_llr || o->ldpc_bytes != o->bch->dec->code().n / 8) { dvbs2_chain_destroy(o); return fail(DVBS2_EINVAL, "inconsistent chain sizes"); }
-    hipError_t e = hipSetDevice(device);
-    if (e == hipSuccess) e = hipMalloc(&o->d_llr, (size_t)max_frames * o->n_llr);
-    if (e == hipSuccess) e = hipMalloc(&o->d_bits, (size_t)max_frames * o->ldpc_bytes);
-    if (e == hipSuccess) e = hipMalloc(&o->d_corr, (size_t)max_frames * 4);
-    if (e != hipSuccess) { dvbs2_chain_destroy(o); return fail(DVBS2_EDEVICE, hipGetErrorString(e)); }
-    *h = o;
-    return DVBS2_OK;
+    return chain_make(h, standard, framesize, rate, constellation, true, group_size, max_frames, device);
+    API_CATCH
+}
+
+int dvbs2_chain_create_llr(dvbs2_chain_t** h, int standard, int framesize, int rate, int group_size, int max_frames, int device)
+{
+    API_TRY
+    return chain_make(h, standard, framesize, rate, 0, false, group_size, max_frames, device);
     API_CATCH
 }
 
 int dvbs2_chain_params(const dvbs2_chain_t* h, int* n_syms, int* msg_bytes)
 {
     if (!h) return fail(DVBS2_EINVAL, "null handle");
-    if (n_syms) *n_syms = h->dm->dm->n_syms();
+    if (n_syms) *n_syms = h->dm ? h->dm->dm->n_syms() : 0;
     if (msg_bytes) *msg_bytes = h->msg_bytes;
     return DVBS2_OK;
+}
+
+int dvbs2_chain_llr_params(const dvbs2_chain_t* h, int* n_llr, int* msg_bytes, int* group_size)
+{
+    if (!h) return fail(DVBS2_EINVAL, "null handle");
+    if (n_llr) *n_llr = h->n_llr;
+    if (msg_bytes) *msg_bytes = h->msg_bytes;
+    if (group_size) *group_size = h->ldpc->dec->group_size();
+    return DVBS2_OK;
+}
+
+int dvbs2_chain_enqueue_device(dvbs2_chain_t* h, const float* d_syms, int n_frames, const float* d_n0, int n0_count,
+                               int max_trials, uint8_t* d_msg, int32_t* d_ldpc_ret, int32_t* d_bch_corr, void* stream)
+{
+    API_TRY
+    if (!h) return fail(DVBS2_EINVAL, "null handle");
+    if (!h->dm) return fail(DVBS2_EINVAL, "this chain starts at LLRs: use dvbs2_chain_enqueue_llr_device");
+    if (h->pending) return fail(DVBS2_EINVAL, "previous call not finished");
+    if (n_frames > h->max_frames) return fail(DVBS2_ESIZE, "n_frames exceeds max_frames");
+    if (n_frames < 0 || max_trials <= 0 || (n_frames && !d_msg)) return fail(DVBS2_EINVAL, "bad argument");
+    if (n_frames == 0) return DVBS2_OK;
+    int rc = dvbs2_demap_soft_device(h->dm, d_syms, n_frames, d_n0, n0_count, h->d_llr, stream);
+    if (rc == DVBS2_OK) rc = chain_enqueue_tail(h, h->d_llr, n_frames, max_trials, d_msg, d_ldpc_ret, d_bch_corr, stream);
+    return rc;
+    API_CATCH
+}
+
+int dvbs2_chain_enqueue_llr_device(dvbs2_chain_t* h, const int8_t* d_llr, int n_frames, int max_trials, uint8_t* d_msg,
+                                   int32_t* d_ldpc_ret, int32_t* d_bch_corr, void* stream)
+{
+    API_TRY
+    if (!h) return fail(DVBS2_EINVAL, "null handle");
+    if (h->pending) return fail(DVBS2_EINVAL, "previous call not finished");
+    if (n_frames > h->max_frames) return fail(DVBS2_ESIZE, "n_frames exceeds max_frames");
+    if (n_frames < 0 || max_trials <= 0 || (n_frames && (!d_llr || !d_msg))) return fail(DVBS2_EINVAL, "bad argument");
+    if (n_frames == 0) return DVBS2_OK;
+    return chain_enqueue_tail(h, d_llr, n_frames, max_trials, d_msg, d_ldpc_ret, d_bch_corr, stream);
+    API_CATCH
+}
+
+int dvbs2_chain_ldpc_profile(dvbs2_chain_t* h, int enable, double* total_ms, int* launches)
+{
+    if (!h) return fail(DVBS2_EINVAL, "null handle");
+    return dvbs2_ldpc_profile(h->ldpc, enable, total_ms, launches);
+}
+
+const char* dvbs2_chain_ldpc_kernel_name(const dvbs2_chain_t* h) { return h ? h->ldpc->dec->kernel_name() : nullptr; }
+
+int dvbs2_chain_finish(dvbs2_chain_t* h)
+{
+    API_TRY
+    if (!h) return fail(DVBS2_EINVAL, "null handle");
+    if (!h->pending) return DVBS2_OK;
+    h->pending = false;
+    const int r = h->ldpc->dec->finish(0); // waits for the stream: demapper, LDPC and BCH of this call are done
+    if (r < 0) return fail(DVBS2_EDEVICE, h->ldpc->dec->error());
+    if (r > 0) { // the LDPC needed rounds beyond the enqueued ones and rewrote its output: run the BCH stage again
+        int rc = dvbs2_bch_decode_device(h->bch, h->d_bits, h->n_frames, h->d_msg, h->d_bch_corr, h->stream);
+        if (rc != DVBS2_OK) return rc;
+        HCHK(hipStreamSynchronize((hipStream_t)h->stream));
+    }
+    return DVBS2_OK;
+    API_CATCH
 }
 
 int dvbs2_chain_decode_device(dvbs2_chain_t* h, const float* d_syms, int n_frames, const float* d_n0, int n0_count,
                               int max_trials, uint8_t* d_msg, int32_t* d_ldpc_ret, int32_t* d_bch_corr, void* stream)
 {
-    API_TRY
-    if (!h) return fail(DVBS2_EINVAL, "null handle");
-    if (n_frames > h->max_frames) return fail(DVBS2_ESIZE, "n_frames exceeds max_frames");
-    int rc = dvbs2_demap_soft_device(h->dm, d_syms, n_frames, d_n0, n0_count, h->d_llr, stream);
-    if (rc == DVBS2_OK) rc = dvbs2_ldpc_decode_device(h->ldpc, h->d_llr, n_frames, max_trials, DVBS2_OM_MESSAGE, h->d_bits, nullptr, d_ldpc_ret, stream);
-    if (rc == DVBS2_OK) rc = dvbs2_bch_decode_device(h->bch, h->d_bits, n_frames, d_msg, d_bch_corr ? d_bch_corr : h->d_corr, stream);
-    return rc;
-    API_CATCH
+    int rc = dvbs2_chain_enqueue_device(h, d_syms, n_frames, d_n0, n0_count, max_trials, d_msg, d_ldpc_ret, d_bch_corr, stream);
+    if (rc != DVBS2_OK) { if (h) h->pending = false; return rc; }
+    return dvbs2_chain_finish(h);
+}
+
+int dvbs2_chain_decode_llr_device(dvbs2_chain_t* h, const int8_t* d_llr, int n_frames, int max_trials, uint8_t* d_msg,
+                                  int32_t* d_ldpc_ret, int32_t* d_bch_corr, void* stream)
+{
+    int rc = dvbs2_chain_enqueue_llr_device(h, d_llr, n_frames, max_trials, d_msg, d_ldpc_ret, d_bch_corr, stream);
+    if (rc != DVBS2_OK) { if (h) h->pending = false; return rc; }
+    return dvbs2_chain_finish(h);
 }
 
 } // extern "C"
@@ -599,7 +777,7 @@ int dvbs2_plpayload_create(dvbs2_plpayload_t** h, int gold_code, int n_slots, in
 void dvbs2_plpayload_destroy(dvbs2_plpayload_t* h)
 {
     if (!h) return;
-    (void)hipSetDevice(h->device);
+    DeviceGuard guard(h->device);
     (void)hipFree(h->d_in); (void)hipFree(h->d_out); (void)hipFree(h->d_par); (void)hipFree(h->d_cc);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h->pp;
@@ -640,7 +818,8 @@ int dvbs2_plpayload_process(dvbs2_plpayload_t* h, const float* payload, int n_fr
         return fail(DVBS2_EINVAL, "bad argument");
     if (n_frames > h->pp->max_frames()) return fail(DVBS2_ESIZE, "n_frames exceeds max_frames");
     if (n_frames == 0) return DVBS2_OK;
-    HCHK(hipSetDevice(h->device));
+    DeviceGuard guard(h->device);
+    if (!guard.ok) return fail(DVBS2_EDEVICE, "hipSetDevice failed");
     const size_t mf = h->pp->max_frames(), pl = h->pp->payload_len(), xl = h->pp->xfecframe_len(), nf = n_frames;
     if (!h->stream) HCHK(hipStreamCreate(&h->stream));
     if (!h->d_in) HCHK(hipMalloc(&h->d_in, mf * pl * 8));

@@ -32,7 +32,21 @@ public:
     // d_bits_out: n_frames * (out_mode ? out_bits_message/8 : N/8) bytes, MSB first.
     // d_llr_out (nullable): n_frames*N decoded LLRs (what the reference publishes as llr_pdu).
     // d_ret (nullable): one int32 per group = the reference decode() return value (trials left, or -1).
-    // Enqueues on `stream` and synchronises it before returning (the group logic needs one flag read).
+    //
+    // enqueue() puts the whole decode on `stream` WITHOUT any host synchronisation: the first pass, kResolveRounds
+    // rounds of (group targets, resume launch -- workgroups with nothing to do leave at once) that resolve the
+    // batch-coupled stopping rule on the device, the output stage, and an asynchronous read-back of the "groups still
+    // unresolved" counter. finish() waits for the stream and, only if that counter is not zero (a group needed more
+    // rounds than were enqueued: a frame that had converged earlier fails the test again at the group's count -- rare),
+    // runs the remaining rounds and the output stage again. Results are final after finish() returned 0.
+    // `slot` (< kSlots) selects the per-call flag storage and `frame_base` the range [frame_base, frame_base + n_frames)
+    // of the handle's state/message buffers, so that several chunks can be in flight on different streams.
+    // decode_device() = enqueue() + finish().
+    static constexpr int kResolveRounds = 2;
+    static constexpr int kSlots = 4;
+    int enqueue(const int8_t* d_llr_in, int n_frames, int max_trials, int out_mode, uint8_t* d_bits_out, int8_t* d_llr_out,
+                int32_t* d_ret, hipStream_t stream, int slot = 0, int frame_base = 0);
+    int finish(int slot = 0); // 0 = done, 1 = done and the outputs were rewritten by extra rounds, -1 = error
     int decode_device(const int8_t* d_llr_in, int n_frames, int max_trials, int out_mode,
                       uint8_t* d_bits_out, int8_t* d_llr_out, int32_t* d_ret, hipStream_t stream);
 
@@ -59,8 +73,15 @@ private:
     int* d_iters_ = nullptr;      // per frame: updates done
     int* d_good_ = nullptr;       // per frame: syndrome satisfied at the current state
     int* d_target_ = nullptr;     // per frame: updates to reach in a resume pass
-    int* d_flag_ = nullptr;       // [0] = number of unresolved groups
-    int* h_flag_ = nullptr;       // pinned
+    int* d_flag_ = nullptr;       // [slot] = number of unresolved groups
+    int* h_flag_ = nullptr;       // pinned, [slot]
+    struct Pending { bool active = false; int n_frames = 0, max_trials = 0, out_mode = 0, frame_base = 0;
+                     uint8_t* bits = nullptr; int8_t* llr_out = nullptr; int32_t* ret = nullptr; hipStream_t stream = nullptr; };
+    Pending pend_[kSlots];
+    int resolve_rounds_ = kResolveRounds;
+    void launch_sweep(const int8_t* in, bool resume, int stop_on_good, int n_frames, int max_trials, int frame_base, hipStream_t stream);
+    void launch_targets(int n_frames, int max_trials, int frame_base, int32_t* d_ret, int slot, hipStream_t stream);
+    void launch_finalize(const Pending& p);
     bool profiling_ = false;
     double prof_ms_ = 0;
     int prof_launches_ = 0;

@@ -148,8 +148,9 @@ LdpcDecoderHip::LdpcDecoderHip(const LdpcTableDesc* table, int out_bits_message,
     HIP_OK(hipMalloc(&d_iters_, (size_t)max_frames_ * 4));
     HIP_OK(hipMalloc(&d_good_, (size_t)max_frames_ * 4));
     HIP_OK(hipMalloc(&d_target_, (size_t)max_frames_ * 4));
-    HIP_OK(hipMalloc(&d_flag_, 4));
-    HIP_OK(hipHostMalloc(&h_flag_, 4));
+    if (const char* e = getenv("DVBS2_RESOLVE_ROUNDS")) resolve_rounds_ = std::max(0, std::min(8, atoi(e))); // tests: 0 forces the host-side leftover path
+    HIP_OK(hipMalloc(&d_flag_, 4 * kSlots));
+    HIP_OK(hipHostMalloc(&h_flag_, 4 * kSlots));
     HIP_OK(hipEventCreate(&ev0_));
     HIP_OK(hipEventCreate(&ev1_));
     if (getenv("DVBS2_TIMING")) { HIP_OK(hipMalloc(&d_tdbg_, (size_t)max_frames_ * 6 * 8 * 8)); HIP_OK(hipMemset(d_tdbg_, 0, (size_t)max_frames_ * 6 * 8 * 8)); }
@@ -181,41 +182,64 @@ LdpcDecoderHip::~LdpcDecoderHip()
     if (ev1_) (void)hipEventDestroy(ev1_);
 }
 
-int LdpcDecoderHip::decode_device(const int8_t* d_llr_in, int n_frames, int max_trials, int out_mode,
-                                  uint8_t* d_bits_out, int8_t* d_llr_out, int32_t* d_ret, hipStream_t stream)
+void LdpcDecoderHip::launch_sweep(const int8_t* in, bool resume, int stop_on_good, int n_frames, int max_trials, int frame_base, hipStream_t stream)
+{
+    if (profiling_) (void)hipEventRecord(ev0_, stream);
+    const size_t fb = (size_t)frame_base;
+    LdpcLaunch la;
+    la.recs = d_recs_; la.llr_in = in; la.state = d_state_ + fb * sched_.N;
+    la.msgs = d_msgs_ + fb * sched_.q * words_per_check_ * kMsgStride;
+    la.iters = d_iters_ + fb; la.good = d_good_ + fb; la.target = resume ? d_target_ + fb : nullptr;
+    la.n_frames = n_frames; la.N = sched_.N; la.K = sched_.K; la.q = sched_.q; la.cap = max_trials; la.stop_on_good = stop_on_good;
+    la.tdbg = d_tdbg_; la.lds_bytes = lds_bytes_; la.stream = stream; la.dense = dense_;
+    if (pr_) ldpc_pr_launch(la);
+    else switch (dmax_) {
+        case 8: ldpc_variant_launch<8>(la); break;   case 12: ldpc_variant_launch<12>(la); break;
+        case 16: ldpc_variant_launch<16>(la); break; case 20: ldpc_variant_launch<20>(la); break;
+        case 24: ldpc_variant_launch<24>(la); break; case 28: ldpc_variant_launch<28>(la); break;
+        case 32: ldpc_variant_launch<32>(la); break;
+    }
+    if (profiling_ && !resume) { // the first pass is the dominant launch; timing it serialises the stream (bench.py's roofline leg only)
+        (void)hipEventRecord(ev1_, stream);
+        (void)hipEventSynchronize(ev1_);
+        float ms = 0; (void)hipEventElapsedTime(&ms, ev0_, ev1_);
+        prof_ms_ += ms; prof_launches_++;
+    }
+}
+
+void LdpcDecoderHip::launch_targets(int n_frames, int max_trials, int frame_base, int32_t* d_ret, int slot, hipStream_t stream)
+{
+    const int n_groups = (n_frames + G_ - 1) / G_;
+    (void)hipMemsetAsync(d_flag_ + slot, 0, 4, stream);
+    hipLaunchKernelGGL(ldpc_group_targets_kernel, dim3((n_groups + 127) / 128), dim3(128), 0, stream,
+                       d_iters_ + frame_base, d_good_ + frame_base, d_target_ + frame_base, d_flag_ + slot, d_ret, n_groups, G_, n_frames, max_trials);
+}
+
+void LdpcDecoderHip::launch_finalize(const Pending& p)
+{
+    const int out_bytes = (p.out_mode ? out_bits_message_ : sched_.N) / 8;
+    hipLaunchKernelGGL(ldpc_finalize_kernel, dim3((sched_.N / 8 + 255) / 256, p.n_frames), dim3(256), 0, p.stream,
+                       d_state_ + (size_t)p.frame_base * sched_.N, p.bits, p.llr_out, sched_.N, sched_.K, sched_.q, out_bytes);
+}
+
+int LdpcDecoderHip::enqueue(const int8_t* d_llr_in, int n_frames, int max_trials, int out_mode, uint8_t* d_bits_out, int8_t* d_llr_out,
+                            int32_t* d_ret, hipStream_t stream, int slot, int frame_base)
 {
     if (!ok()) return -1;
     call_err_.clear();
-    if (n_frames < 0 || n_frames > max_frames_) { call_err_ = "n_frames exceeds max_frames"; return -1; }
-    if (n_frames == 0) return 0;
+    if (slot < 0 || slot >= kSlots) { call_err_ = "bad slot"; return -1; }
+    if (pend_[slot].active) { call_err_ = "slot busy: finish() the previous decode first"; return -1; }
+    if (n_frames < 0 || frame_base < 0 || frame_base + n_frames > max_frames_) { call_err_ = "n_frames exceeds max_frames"; return -1; }
+    if (frame_base % 2 || (frame_base && frame_base % G_)) { call_err_ = "frame_base must be a multiple of the group size and even"; return -1; }
     if (max_trials < 0) { call_err_ = "max_trials < 0"; return -1; }
+    Pending& p = pend_[slot];
+    p.active = true; p.n_frames = n_frames; p.max_trials = max_trials; p.out_mode = out_mode; p.frame_base = frame_base;
+    p.bits = d_bits_out; p.llr_out = d_llr_out; p.ret = d_ret; p.stream = stream;
+    h_flag_[slot] = 0;
+    if (n_frames == 0) return 0;
     DeviceGuard dev_guard(device_);
-    if (!dev_guard.ok) { call_err_ = "hipSetDevice failed"; return -1; }
-    const size_t lds_bytes = lds_bytes_;
-    auto launch = [&](const int8_t* in, const int* target, int stop_on_good) {
-        if (profiling_) (void)hipEventRecord(ev0_, stream);
-        LdpcLaunch la;
-        la.recs = d_recs_; la.llr_in = in; la.state = d_state_; la.msgs = d_msgs_; la.iters = d_iters_; la.good = d_good_; la.target = target;
-        la.n_frames = n_frames; la.N = sched_.N; la.K = sched_.K; la.q = sched_.q; la.cap = max_trials; la.stop_on_good = stop_on_good;
-        la.tdbg = d_tdbg_; la.lds_bytes = lds_bytes; la.stream = stream; la.dense = dense_;
-        if (pr_) ldpc_pr_launch(la);
-        else switch (dmax_) {
-            case 8: ldpc_variant_launch<8>(la); break;   case 12: ldpc_variant_launch<12>(la); break;
-            case 16: ldpc_variant_launch<16>(la); break; case 20: ldpc_variant_launch<20>(la); break;
-            case 24: ldpc_variant_launch<24>(la); break; case 28: ldpc_variant_launch<28>(la); break;
-            case 32: ldpc_variant_launch<32>(la); break;
-        }
-        if (profiling_) {
-            (void)hipEventRecord(ev1_, stream);
-            (void)hipEventSynchronize(ev1_);
-            float ms = 0; (void)hipEventElapsedTime(&ms, ev0_, ev1_);
-            prof_ms_ += ms; prof_launches_++;
-        }
-    };
-    // bnl = 0 before the first update (layered_decoder.hh:27-31,149): both sweep kernels take zero messages in the first
-    // sweep of a fresh decode instead of reading them (no memset of the message records)
-    launch(d_llr_in, nullptr, 1);
-    HIP_RET(hipGetLastError());
+    if (!dev_guard.ok) { p.active = false; call_err_ = "hipSetDevice failed"; return -1; }
+    launch_sweep(d_llr_in, false, 1, n_frames, max_trials, frame_base, stream);
     if (d_tdbg_) {
         HIP_RET(hipStreamSynchronize(stream));
         std::vector<unsigned long long> h((size_t)n_frames * 48);
@@ -232,24 +256,49 @@ int LdpcDecoderHip::decode_device(const int8_t* d_llr_in, int n_frames, int max_
         }
         fprintf(stderr, "[timing, shader-clock cycles per wave avg] load %.0f synd %.0f sweep %.0f (barrier %.0f body %.0f conflict-layers %.0f) iters %.1f synd-step1 %.0f\n", a[0]/nr, a[1]/nr, a[2]/nr, a[3]/nr, a[4]/nr, a[5]/nr, a[6]/nr, a[7]/nr);
     }
-    const int n_groups = (n_frames + G_ - 1) / G_;
-    for (int round = 0;; round++) {
-        HIP_RET(hipMemsetAsync(d_flag_, 0, 4, stream));
-        hipLaunchKernelGGL(ldpc_group_targets_kernel, dim3((n_groups + 127) / 128), dim3(128), 0, stream,
-                           d_iters_, d_good_, d_target_, d_flag_, d_ret, n_groups, G_, n_frames, max_trials);
-        HIP_RET(hipMemcpyAsync(h_flag_, d_flag_, 4, hipMemcpyDeviceToHost, stream));
-        HIP_RET(hipStreamSynchronize(stream));
-        if (*h_flag_ == 0) break;
-        if (round > 2 * max_trials + 2) { call_err_ = "group resolution did not converge"; return -1; }
-        launch(nullptr, d_target_, 0);
-        HIP_RET(hipGetLastError());
+    // group resolution on the device: no host round trip (a resume launch whose frames are all at their target costs a few
+    // microseconds: its workgroups read two counters and leave)
+    for (int r = 0; r < resolve_rounds_; r++) {
+        launch_targets(n_frames, max_trials, frame_base, d_ret, slot, stream);
+        launch_sweep(nullptr, true, 0, n_frames, max_trials, frame_base, stream);
     }
-    const int out_bytes = (out_mode ? out_bits_message_ : sched_.N) / 8;
-    hipLaunchKernelGGL(ldpc_finalize_kernel, dim3((sched_.N / 8 + 255) / 256, n_frames), dim3(256), 0, stream,
-                       d_state_, d_bits_out, d_llr_out, sched_.N, sched_.K, sched_.q, out_bytes);
+    launch_targets(n_frames, max_trials, frame_base, d_ret, slot, stream);
+    launch_finalize(p);
+    HIP_RET(hipMemcpyAsync(h_flag_ + slot, d_flag_ + slot, 4, hipMemcpyDeviceToHost, stream));
     HIP_RET(hipGetLastError());
-    HIP_RET(hipStreamSynchronize(stream));
     return 0;
+}
+
+int LdpcDecoderHip::finish(int slot)
+{
+    if (!ok()) return -1;
+    if (slot < 0 || slot >= kSlots) { call_err_ = "bad slot"; return -1; }
+    Pending& p = pend_[slot];
+    if (!p.active) return 0;
+    p.active = false;
+    if (p.n_frames == 0) return 0;
+    DeviceGuard dev_guard(device_);
+    if (!dev_guard.ok) { call_err_ = "hipSetDevice failed"; return -1; }
+    HIP_RET(hipStreamSynchronize(p.stream));
+    if (h_flag_[slot] == 0) return 0;
+    for (int round = 0; h_flag_[slot] != 0; round++) { // the rare leftovers, one host round trip each
+        if (round > 2 * p.max_trials + 2) { call_err_ = "group resolution did not converge"; return -1; }
+        launch_sweep(nullptr, true, 0, p.n_frames, p.max_trials, p.frame_base, p.stream);
+        launch_targets(p.n_frames, p.max_trials, p.frame_base, p.ret, slot, p.stream);
+        HIP_RET(hipMemcpyAsync(h_flag_ + slot, d_flag_ + slot, 4, hipMemcpyDeviceToHost, p.stream));
+        HIP_RET(hipStreamSynchronize(p.stream));
+    }
+    launch_finalize(p);
+    HIP_RET(hipGetLastError());
+    HIP_RET(hipStreamSynchronize(p.stream));
+    return 1; // outputs were rewritten after the stream's first completion
+}
+
+int LdpcDecoderHip::decode_device(const int8_t* d_llr_in, int n_frames, int max_trials, int out_mode,
+                                  uint8_t* d_bits_out, int8_t* d_llr_out, int32_t* d_ret, hipStream_t stream)
+{
+    if (enqueue(d_llr_in, n_frames, max_trials, out_mode, d_bits_out, d_llr_out, d_ret, stream, 0, 0)) return -1;
+    return finish(0) < 0 ? -1 : 0;
 }
 
 } // namespace dvbs2

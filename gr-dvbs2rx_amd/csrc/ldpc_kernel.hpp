@@ -449,6 +449,12 @@ __global__ __launch_bounds__(kThreads, MINW) void ldpc_layered_kernel(
     unsigned long long tm_bar = 0, tm_body = 0, tm_conf = 0, tm_synd = 0, tm_sweep = 0, tm_load = 0, tm_s1 = 0;
 #define TSTAMP(x) do { if (TIMING) { x = __builtin_readcyclecounter(); } } while (0)
     unsigned long long tA = 0, tB = 0, tC = 0, tS0 = 0, tS1 = 0;
+    if (!llr_in) { // resume launch: a workgroup whose frames are both at their target leaves before touching LDS
+        const int fa = 2 * (int)blockIdx.x, fb = fa + 1;
+        const bool ta = fa < n_frames && iters[fa] < target[fa];
+        const bool tb = fb < n_frames && iters[fb] < target[fb];
+        if (!ta && !tb) return;
+    }
     TSTAMP(tA);
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_all[];
     constexpr int RS = rec_stride(DMAX);

@@ -42,6 +42,12 @@ __global__ __launch_bounds__(kThreads, 6) void ldpc_layered_pr_kernel(
     uint32_t* __restrict__ msgs, int* __restrict__ iters, int* __restrict__ good, const int* __restrict__ target,
     int n_frames, int N, int K, int q, int cap, int stop_on_good)
 {
+    if (!llr_in) { // resume launch: a workgroup whose frames are both at their target leaves before touching LDS
+        const int fa = 2 * (int)blockIdx.x, fb = fa + 1;
+        const bool ta = fa < n_frames && iters[fa] < target[fa];
+        const bool tb = fb < n_frames && iters[fb] < target[fb];
+        if (!ta && !tb) return;
+    }
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_all[];
     constexpr int DMAX = 8, RS = rec_stride(DMAX), MW = 2;
     const int half = __builtin_amdgcn_readfirstlane(threadIdx.x >= kHalf ? 1 : 0);

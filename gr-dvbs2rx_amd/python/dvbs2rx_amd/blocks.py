@@ -135,6 +135,14 @@ class LdpcDecoder:
         check(lib.dvbs2_ldpc_decode_device(self._h, d_llr, n_frames, self.max_trials, self.outputmode,
                                            d_bits, d_llr_out or None, d_ret or None, stream or None))
 
+    def enqueue_device(self, d_llr, n_frames, d_bits, d_llr_out=0, d_ret=0, stream=0):
+        """work_device without the host synchronisation; finish() completes it."""
+        check(lib.dvbs2_ldpc_enqueue_device(self._h, d_llr, n_frames, self.max_trials, self.outputmode,
+                                            d_bits, d_llr_out or None, d_ret or None, stream or None))
+
+    def finish(self):
+        check(lib.dvbs2_ldpc_finish(self._h))
+
     @property
     def kernel_name(self):
         return lib.dvbs2_ldpc_kernel_name(self._h).decode()
@@ -297,13 +305,18 @@ class FecChain:
     """demapper -> LDPC (OM_MESSAGE) -> BCH on the device, as wired in apps/dvbs2-rx:853-863."""
 
     def __init__(self, standard=capi.STANDARD_DVBS2, framesize=capi.FECFRAME_NORMAL, rate="C3_4",
-                 constellation=capi.MOD_8PSK, group_size=32, max_frames=64, max_trials=0, device=0):
+                 constellation=capi.MOD_8PSK, group_size=32, max_frames=64, max_trials=0, device=0, from_llr=False):
         self._h = C.c_void_p()
-        check(lib.dvbs2_chain_create(C.byref(self._h), standard, framesize, rate_id(rate), constellation,
-                                     group_size, max_frames, device))
+        if from_llr:  # ldpc_decoder_bb -> bch_decoder_bb only (LLRs in)
+            check(lib.dvbs2_chain_create_llr(C.byref(self._h), standard, framesize, rate_id(rate), group_size, max_frames, device))
+        else:
+            check(lib.dvbs2_chain_create(C.byref(self._h), standard, framesize, rate_id(rate), constellation,
+                                         group_size, max_frames, device))
         a, b = C.c_int(), C.c_int()
         check(lib.dvbs2_chain_params(self._h, a, b))
         self.n_syms, self.msg_bytes = a.value, b.value
+        check(lib.dvbs2_chain_llr_params(self._h, a, b, None))
+        self.n_llr = a.value
         self.group_size = group_size
         self.max_trials = DEFAULT_TRIALS if max_trials == 0 else max_trials
 
@@ -324,3 +337,27 @@ class FecChain:
     def work_device(self, d_syms, n_frames, d_n0, n0_count, d_msg, d_ldpc_ret=0, d_bch_corr=0, stream=0):
         check(lib.dvbs2_chain_decode_device(self._h, d_syms, n_frames, d_n0, n0_count, self.max_trials, d_msg,
                                             d_ldpc_ret or None, d_bch_corr or None, stream or None))
+
+    def work_llr_device(self, d_llr, n_frames, d_msg, d_ldpc_ret=0, d_bch_corr=0, stream=0):
+        check(lib.dvbs2_chain_decode_llr_device(self._h, d_llr, n_frames, self.max_trials, d_msg,
+                                                d_ldpc_ret or None, d_bch_corr or None, stream or None))
+
+    def enqueue_device(self, d_syms, n_frames, d_n0, n0_count, d_msg, d_ldpc_ret=0, d_bch_corr=0, stream=0):
+        check(lib.dvbs2_chain_enqueue_device(self._h, d_syms, n_frames, d_n0, n0_count, self.max_trials, d_msg,
+                                             d_ldpc_ret or None, d_bch_corr or None, stream or None))
+
+    def enqueue_llr_device(self, d_llr, n_frames, d_msg, d_ldpc_ret=0, d_bch_corr=0, stream=0):
+        check(lib.dvbs2_chain_enqueue_llr_device(self._h, d_llr, n_frames, self.max_trials, d_msg,
+                                                 d_ldpc_ret or None, d_bch_corr or None, stream or None))
+
+    def finish(self):
+        check(lib.dvbs2_chain_finish(self._h))
+
+    @property
+    def kernel_name(self):
+        return lib.dvbs2_chain_ldpc_kernel_name(self._h).decode()
+
+    def profile(self, enable=True):
+        ms, n = C.c_double(), C.c_int()
+        check(lib.dvbs2_chain_ldpc_profile(self._h, 1 if enable else 0, ms, n))
+        return ms.value, n.value

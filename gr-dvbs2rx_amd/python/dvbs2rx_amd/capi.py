@@ -37,6 +37,8 @@ _vp, _i, _ip = C.c_void_p, C.c_int, C.POINTER(C.c_int)
 SYMBOLS = {
     "dvbs2_last_error": (C.c_char_p, []),
     "dvbs2_device_count": (_i, []),
+    "dvbs2_host_register": (_i, [_vp, C.c_size_t]),
+    "dvbs2_host_unregister": (_i, [_vp]),
     "dvbs2_get_fec_info": (_i, [_i, _i, _i, C.POINTER(FecInfo)]),
     "dvbs2_rate_name": (C.c_char_p, [_i]),
     "dvbs2_rate_from_name": (_i, [C.c_char_p]),
@@ -49,6 +51,8 @@ SYMBOLS = {
     "dvbs2_ldpc_params": (_i, [_vp, _ip, _ip, _ip, _ip, _ip]),
     "dvbs2_ldpc_decode": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "dvbs2_ldpc_decode_device": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "dvbs2_ldpc_enqueue_device": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "dvbs2_ldpc_finish": (_i, [_vp]),
     "dvbs2_ldpc_profile": (_i, [_vp, _i, C.POINTER(C.c_double), _ip]),
     "dvbs2_ldpc_kernel_name": (C.c_char_p, [_vp]),
     "dvbs2_bch_create": (_i, [C.POINTER(_vp), _i, _i, _i, _i, _i]),
@@ -80,6 +84,14 @@ SYMBOLS = {
     "dvbs2_chain_params": (_i, [_vp, _ip, _ip]),
     "dvbs2_chain_set_descramble": (_i, [_vp, _i]),
     "dvbs2_chain_decode_device": (_i, [_vp, _vp, _i, _vp, _i, _i, _vp, _vp, _vp, _vp]),
+    "dvbs2_chain_create_llr": (_i, [C.POINTER(_vp), _i, _i, _i, _i, _i, _i]),
+    "dvbs2_chain_llr_params": (_i, [_vp, _ip, _ip, _ip]),
+    "dvbs2_chain_decode_llr_device": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
+    "dvbs2_chain_enqueue_device": (_i, [_vp, _vp, _i, _vp, _i, _i, _vp, _vp, _vp, _vp]),
+    "dvbs2_chain_enqueue_llr_device": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
+    "dvbs2_chain_finish": (_i, [_vp]),
+    "dvbs2_chain_ldpc_profile": (_i, [_vp, _i, C.POINTER(C.c_double), _ip]),
+    "dvbs2_chain_ldpc_kernel_name": (C.c_char_p, [_vp]),
 }
 
 if not os.path.exists(LIB_PATH):

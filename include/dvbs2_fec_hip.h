@@ -18,6 +18,7 @@
 #ifndef DVBS2_FEC_HIP_H
 #define DVBS2_FEC_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -47,6 +48,12 @@ extern "C" {
 
 const char* dvbs2_last_error(void);
 int dvbs2_device_count(void);
+
+/* Page-lock a host buffer that the block hands to the plain (host-pointer) entry points again and again -- e.g. a GNU
+ * Radio input buffer, once, at start() -- so that the transfers run at PCIe speed and asynchronously (pageable memory
+ * goes through a staging copy at a fraction of it and blocks the calling thread). Optional; undo before freeing. */
+int dvbs2_host_register(void* p, size_t bytes);
+int dvbs2_host_unregister(void* p);
 
 /* ---- parameter map: replaces get_fec_info(), reference lib/fec_params.h:36-39 / fec_params.cc:16-344,
  * plus the table selection of lib/ldpc_decoder_bb_impl.cc:104-307 ---- */
@@ -97,6 +104,16 @@ int dvbs2_ldpc_decode(dvbs2_ldpc_t* h, const int8_t* llr_in, int n_frames, int m
 int dvbs2_ldpc_decode_device(dvbs2_ldpc_t* h, const int8_t* d_llr_in, int n_frames, int max_trials,
                              int out_mode, uint8_t* d_bits_out, int8_t* d_llr_out, int32_t* d_ret,
                              void* stream);
+/* The same decode WITHOUT host synchronisation: everything (first pass, the device-side resolution of the batch-coupled
+ * stopping rule, the output stage) is enqueued on `stream` and the call returns; dvbs2_ldpc_finish() waits for the stream
+ * and completes the rare group that needed more rounds than were enqueued. Outputs are final once finish() returned
+ * DVBS2_OK; one decode may be outstanding per handle. dvbs2_ldpc_decode_device == enqueue + finish. This is what lets a
+ * block overlap the transfers and neighbours of batch k + 1 with the LDPC of batch k
+ * (reference call site: lib/ldpc_decoder_bb_impl.cc:406-449, one blocking call per SIMD batch). */
+int dvbs2_ldpc_enqueue_device(dvbs2_ldpc_t* h, const int8_t* d_llr_in, int n_frames, int max_trials,
+                              int out_mode, uint8_t* d_bits_out, int8_t* d_llr_out, int32_t* d_ret,
+                              void* stream);
+int dvbs2_ldpc_finish(dvbs2_ldpc_t* h);
 /* HIP-event timing of the dominant kernel (the layered update sweep) on its launch stream.
  * enable != 0 starts/reset accumulation; reads back total milliseconds and launch count. */
 int dvbs2_ldpc_profile(dvbs2_ldpc_t* h, int enable, double* total_ms, int* launches);
@@ -180,6 +197,13 @@ int dvbs2_chain_create(dvbs2_chain_t** h, int standard, int framesize, int rate,
 void dvbs2_chain_destroy(dvbs2_chain_t* h);
 /* bytes per frame out (bch k / 8), symbols per frame in */
 int dvbs2_chain_params(const dvbs2_chain_t* h, int* n_syms, int* msg_bytes);
+/* The chain from LLRs (ldpc_decoder_bb -> bch_decoder_bb, apps/dvbs2-rx:857-863): for constellations whose soft demapper
+ * is not part of the reference (lib/xfecframe_demapper_cb_impl.cc:70-72 rejects everything but QPSK and 8PSK) the LLRs
+ * come from elsewhere; this is BASELINE config "9/10 normal" run from int8 LLRs. */
+int dvbs2_chain_create_llr(dvbs2_chain_t** h, int standard, int framesize, int rate, int group_size, int max_frames,
+                           int device);
+/* LLRs per frame in (N), bytes per frame out (bch k / 8), group size */
+int dvbs2_chain_llr_params(const dvbs2_chain_t* h, int* n_llr, int* msg_bytes, int* group_size);
 /* also apply bbdescrambler_bb in the BCH output stage (dvbs2_bch_set_descramble) */
 int dvbs2_chain_set_descramble(dvbs2_chain_t* h, int enable);
 /* d_msg: n_frames * bch_k/8; d_ldpc_ret (nullable): one per LDPC group; d_bch_corr (nullable -> internal): per frame */
@@ -199,6 +223,20 @@ int dvbs2_chain_decode_device(dvbs2_chain_t* h, const float* d_syms, int n_frame
  * xfecframes  n_frames * 90 n_slots complex symbols: the input of dvbs2_demap_soft
  * The rotator is a float recurrence in the reference (VOLK); here the phase of every symbol is evaluated directly:
  * equal within 1e-4 absolute per component for unit-energy symbols, not bit-exact. */
+/* d_llr: n_frames * N int8 LLRs (works on chains of either kind) */
+int dvbs2_chain_decode_llr_device(dvbs2_chain_t* h, const int8_t* d_llr, int n_frames, int max_trials, uint8_t* d_msg,
+                                  int32_t* d_ldpc_ret, int32_t* d_bch_corr, void* stream);
+/* enqueue-only variants + finish, as for the LDPC decoder: all kernels of the call go to `stream` (demapper, LDPC,
+ * BCH back to back, nothing waits on the host), one call may be outstanding per handle */
+int dvbs2_chain_enqueue_device(dvbs2_chain_t* h, const float* d_syms, int n_frames, const float* d_n0, int n0_count,
+                               int max_trials, uint8_t* d_msg, int32_t* d_ldpc_ret, int32_t* d_bch_corr, void* stream);
+int dvbs2_chain_enqueue_llr_device(dvbs2_chain_t* h, const int8_t* d_llr, int n_frames, int max_trials, uint8_t* d_msg,
+                                   int32_t* d_ldpc_ret, int32_t* d_bch_corr, void* stream);
+int dvbs2_chain_finish(dvbs2_chain_t* h);
+/* dvbs2_ldpc_profile / dvbs2_ldpc_kernel_name of the chain's LDPC stage (the dominant kernel) */
+int dvbs2_chain_ldpc_profile(dvbs2_chain_t* h, int enable, double* total_ms, int* launches);
+const char* dvbs2_chain_ldpc_kernel_name(const dvbs2_chain_t* h);
+
 typedef struct dvbs2_plpayload dvbs2_plpayload_t;
 int dvbs2_plpayload_create(dvbs2_plpayload_t** h, int gold_code, int n_slots, int has_pilots, int max_frames, int device);
 void dvbs2_plpayload_destroy(dvbs2_plpayload_t* h);

@@ -318,3 +318,44 @@ def test_chain_8psk_3_4_normal():
     assert d_corr.cpu().numpy().tolist() == want_corr.tolist()
     assert np.array_equal(d_msg.cpu().numpy(), T.oracle_bb_descramble(want_msg))
     chain.close()
+
+
+# ------------------------------------------------------------------ LLR-domain chain (BASELINE config 5 shape, small batch)
+@pytest.mark.parametrize("rate", ["C9_10", "C154_180"])
+def test_chain_from_llrs(rate):
+    """ldpc_decoder_bb -> bch_decoder_bb from int8 LLRs: 9/10 normal = DVB_S2_TABLE_B11 + BCH(58320, 58192, t = 8), and the
+    genuine S2X table 154/180 = DVB_S2X_TABLE_B21 + BCH(55440, 55248, t = 12). Frames: decodable, one with a few bit
+    errors left for the BCH code (LLR signs flipped hard), one hopeless (noise): vs genuine LDPC reference + BCH oracle."""
+    import torch
+    fi = get_fec_info(capi.STANDARD_DVBS2, capi.FECFRAME_NORMAL, rate)
+    ob, _ = bch_pair(capi.FECFRAME_NORMAL, rate)
+    nf, G, cap = 32, 32, 20
+    rng = np.random.default_rng(91)
+    msg = rng.integers(0, 256, (nf, fi["bch_k"] // 8), dtype=np.uint8)
+    cw = T.ldpc_encode(fi["table"], np.unpackbits(ob.encode_bytes(msg), axis=1))
+    N = cw.shape[1]
+    llr = np.clip(np.rint((1.0 - 2.0 * cw) * 9.0 + rng.normal(0, 3.3, cw.shape)), -128, 127).astype(np.int8)
+    llr[nf - 1] = T.llr_noise(1, N, 5)[0]
+    chain = FecChain(rate=rate, group_size=G, max_frames=nf, max_trials=cap, from_llr=True)
+    assert (chain.n_llr, chain.msg_bytes, chain.n_syms) == (N, fi["bch_k"] // 8, 0)
+    d_llr = torch.from_numpy(llr).cuda()
+    d_msg = torch.empty((nf, chain.msg_bytes), dtype=torch.uint8, device="cuda")
+    d_ret = torch.empty(1, dtype=torch.int32, device="cuda")
+    d_corr = torch.empty(nf, dtype=torch.int32, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    chain.work_llr_device(d_llr.data_ptr(), nf, d_msg.data_ptr(), d_ret.data_ptr(), d_corr.data_ptr(), st)
+    if T.ref_ldpc() is not None:
+        dec_llr, wret = T.ref_ldpc_decode(fi["table"], llr, 0, cap)
+    else:
+        dec_llr, wret = T.oracle_ldpc_decode(fi["table"], llr, G, cap)
+    want_msg, want_corr = ob.decode_bytes(T.pack_bits(dec_llr, fi["bch_n"]))
+    assert d_ret.cpu().tolist() == wret
+    assert d_corr.cpu().numpy().tolist() == want_corr.tolist()
+    assert np.array_equal(d_msg.cpu().numpy(), want_msg)
+    assert np.array_equal(want_msg[:nf - 1], msg[:nf - 1]) and want_corr[nf - 1] < 0
+    # enqueue / finish give the same bytes
+    d_msg2 = torch.zeros_like(d_msg)
+    chain.enqueue_llr_device(d_llr.data_ptr(), nf, d_msg2.data_ptr(), d_ret.data_ptr(), d_corr.data_ptr(), st)
+    chain.finish()
+    assert torch.equal(d_msg, d_msg2)
+    chain.close()

@@ -253,3 +253,33 @@ def test_full_batch_properties(table, nf, trials, amp, sigma):
     want, wret = checker(table, llr[lo:lo + base], 32, trials)
     assert np.array_equal(o3, want) and r3.tolist() == wret
     dec.close()
+
+
+def test_async_entry_and_chunked_host_path(monkeypatch):
+    """dvbs2_ldpc_enqueue_device + dvbs2_ldpc_finish == dvbs2_ldpc_decode_device; the host entry (chunks of whole groups
+    on two streams) == the device entry; and with no device-side resolution rounds enqueued (DVBS2_RESOLVE_ROUNDS=0) the
+    host-side leftover rounds of finish() give the same result (near-threshold input: groups need resume passes)."""
+    import torch
+    table = "S2_TABLE_C1"
+    N, K, _, _ = T.ldpc_info(table)
+    nf, G, cap = 416, 32, 25  # 13 groups: the host path splits it into chunks of 128 frames
+    llr, _ = T.llr_codeword_awgn(table, nf, 2025, amp=5, sigma=6.0)
+    want, wret = checker(table, llr, G, cap)
+    assert len(set(wret)) > 2  # groups stop at different counts: the stopping rule is exercised
+    st = torch.cuda.current_stream().cuda_stream
+    for rounds in (None, "0"):
+        if rounds is not None:
+            monkeypatch.setenv("DVBS2_RESOLVE_ROUNDS", rounds)
+        dec = LdpcDecoder(table=table, message_bits=K, group_size=G, max_frames=nf, max_trials=cap, outputmode=capi.OM_MESSAGE)
+        d_in = torch.from_numpy(llr).cuda()
+        d_bits = torch.zeros((nf, K // 8), dtype=torch.uint8, device="cuda")
+        d_out = torch.zeros((nf, N), dtype=torch.int8, device="cuda")
+        d_ret = torch.zeros(nf // G, dtype=torch.int32, device="cuda")
+        dec.enqueue_device(d_in.data_ptr(), nf, d_bits.data_ptr(), d_out.data_ptr(), d_ret.data_ptr(), st)
+        dec.finish()
+        assert d_ret.cpu().tolist() == wret
+        assert np.array_equal(d_out.cpu().numpy(), want)
+        assert np.array_equal(d_bits.cpu().numpy(), T.pack_bits(want, K))
+        bits, out, ret = dec.work(llr, want_llr=True)  # host buffers, chunked
+        assert ret.tolist() == wret and np.array_equal(out, want) and np.array_equal(bits, T.pack_bits(want, K))
+        dec.close()
