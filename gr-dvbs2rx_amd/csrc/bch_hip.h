@@ -33,7 +33,10 @@ public:
     // DEVICE pointers. d_cw: n_frames * n/8 bytes (first bit = x^(n-1), reference lib/bch.cc:436-449);
     // d_msg: n_frames * k/8 bytes; d_corr: per frame  >= 0 corrected bits, -1 failure, -2 the reference would
     // have thrown (lib/gf.h:110 via lib/bch.cc:359-367, or lib/bch.cc:443-444).
-    int decode_device(const uint8_t* d_cw, int n_frames, uint8_t* d_msg, int32_t* d_corr, hipStream_t stream);
+    // d_cw == nullptr: the codewords are the hard decisions of d_llr_state (offset-binary LLR bytes, llr_stride per frame: the LDPC
+    // decoder's state) -- ldpc_decoder_bb's bit packing fused into this kernel's load
+    int decode_device(const uint8_t* d_cw, int n_frames, uint8_t* d_msg, int32_t* d_corr, hipStream_t stream,
+                      const uint8_t* d_llr_state = nullptr, int llr_stride = 0);
     // fuse bbdescrambler_bb (lib/bbdescrambler_bb_impl.cc:67-82) into the output stage: msg ^= PRBS
     int set_descramble(bool enable);
 

@@ -78,6 +78,8 @@ constexpr int kBchWorkWords = 640; // dwords of per-workgroup scratch between th
 struct BchArgs {
     const uint16_t* antilog; const uint16_t* log; const uint16_t* quad;
     const uint8_t* cw; uint8_t* msg; int32_t* corr;
+    const uint8_t* llr_state; int llr_stride; // cw == nullptr: the codeword bits are the hard decisions of these offset-binary LLR
+                                              // bytes (the LDPC decoder's state, information part in natural order): bit = byte < 0x80
     const uint8_t* descramble; // k/8 bytes of the BB PRBS or nullptr (fused bbdescrambler_bb)
     int n_frames, m, P, t, n, k, s;
 };
@@ -116,10 +118,17 @@ __global__ __launch_bounds__(kBchThreads) void bch_decode_kernel(BchArgs a)
 
     for (int f = blockIdx.x; f < a.n_frames; f += gridDim.x) {
         __syncthreads();
-        const uint8_t* cw = a.cw + (size_t)f * nb;
         uint8_t* out = a.msg + (size_t)f * kb;
         for (int b = tid; b < nb; b += kBchThreads) { // lib/bch.cc:471 (+ lib/bbdescrambler_bb_impl.cc:74-78 when fused)
-            const uint8_t v = cw[b]; cwl[b] = v;
+            uint8_t v;
+            if (a.cw) v = a.cw[(size_t)f * nb + b];
+            else { // hard decision + MSB-first packing of ldpc_decoder_bb (lib/ldpc_decoder_bb_impl.cc:432-442), fused here
+                const uint2 w = *reinterpret_cast<const uint2*>(a.llr_state + (size_t)f * a.llr_stride + 8 * b);
+                const uint32_t lo = ~w.x & 0x80808080u, hi = ~w.y & 0x80808080u; // bit 7 of every byte: 1 where the LLR is negative
+                v = (uint8_t)((((lo >> 7) & 1u) << 7) | (((lo >> 15) & 1u) << 6) | (((lo >> 23) & 1u) << 5) | ((lo >> 31) << 4) |
+                              (((hi >> 7) & 1u) << 3) | (((hi >> 15) & 1u) << 2) | (((hi >> 23) & 1u) << 1) | (hi >> 31));
+            }
+            cwl[b] = v;
             if (b < kb) out[b] = a.descramble ? (uint8_t)(v ^ a.descramble[b]) : v;
         }
         if (tid < 2 * kMaxT) S[tid] = 0;
@@ -318,7 +327,8 @@ BchDecoderHip::~BchDecoderHip()
     (void)hipFree(d_antilog_); (void)hipFree(d_log_); (void)hipFree(d_quad_);
 }
 
-int BchDecoderHip::decode_device(const uint8_t* d_cw, int n_frames, uint8_t* d_msg, int32_t* d_corr, hipStream_t stream)
+int BchDecoderHip::decode_device(const uint8_t* d_cw, int n_frames, uint8_t* d_msg, int32_t* d_corr, hipStream_t stream,
+                                 const uint8_t* d_llr_state, int llr_stride)
 {
     if (!ok()) return -1;
     call_err_.clear();
@@ -327,7 +337,7 @@ int BchDecoderHip::decode_device(const uint8_t* d_cw, int n_frames, uint8_t* d_m
     DeviceGuard dev_guard(device_);
     if (!dev_guard.ok) { call_err_ = "hipSetDevice failed"; return -1; }
     BchArgs a;
-    a.antilog = d_antilog_; a.log = d_log_; a.quad = d_quad_; a.cw = d_cw; a.msg = d_msg; a.corr = d_corr;
+    a.antilog = d_antilog_; a.log = d_log_; a.quad = d_quad_; a.cw = d_cw; a.msg = d_msg; a.corr = d_corr; a.llr_state = d_llr_state; a.llr_stride = llr_stride;
     a.descramble = descramble_ ? d_scramble_ : nullptr;
     a.n_frames = n_frames; a.m = code_.m; a.P = code_.P; a.t = code_.t; a.n = code_.n; a.k = code_.k; a.s = code_.s;
     const int grid = std::min(n_frames, std::max(1, n_cus_));

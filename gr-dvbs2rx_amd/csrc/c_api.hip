@@ -11,6 +11,7 @@
 #include "demap_hip.h"
 #include "plpayload_hip.h"
 #include "device_guard.h"
+#include "demap_math.hpp"
 #include <algorithm>
 
 using namespace dvbs2;
@@ -610,13 +611,23 @@ static int chain_make(dvbs2_chain_t** h, int standard, int framesize, int rate, 
 }
 
 // LDPC (already enqueued) -> BCH on the same stream; the LDPC output never leaves HBM
-static int chain_enqueue_tail(dvbs2_chain_t* h, const int8_t* d_llr, int n_frames, int max_trials, uint8_t* d_msg,
+// BCH straight from the LDPC decoder's state (hard decision + packing of ldpc_decoder_bb fused into the BCH kernel's load: no
+// finalize launch, no packed-bit buffer in between)
+static int chain_bch(dvbs2_chain_t* h)
+{
+    if (h->bch->dec->decode_device(nullptr, h->n_frames, h->d_msg, h->d_bch_corr, (hipStream_t)h->stream, h->ldpc->dec->state(), h->ldpc->dec->N()))
+        return fail(DVBS2_EDEVICE, h->bch->dec->error());
+    return DVBS2_OK;
+}
+
+// LDPC -> BCH on one stream; dm != nullptr: the LDPC sweep kernel demaps the symbols while it loads them
+static int chain_enqueue_tail(dvbs2_chain_t* h, const int8_t* d_llr, const DemapFused* dm, int n_frames, int max_trials, uint8_t* d_msg,
                               int32_t* d_ldpc_ret, int32_t* d_bch_corr, void* stream)
 {
-    if (h->ldpc->dec->enqueue(d_llr, n_frames, max_trials, DVBS2_OM_MESSAGE, h->d_bits, nullptr, d_ldpc_ret, (hipStream_t)stream, 0, 0))
+    if (h->ldpc->dec->enqueue(d_llr, n_frames, max_trials, DVBS2_OM_MESSAGE, nullptr, nullptr, d_ldpc_ret, (hipStream_t)stream, 0, 0, dm))
         return fail(DVBS2_EDEVICE, h->ldpc->dec->error());
     h->pending = true; h->n_frames = n_frames; h->d_msg = d_msg; h->d_bch_corr = d_bch_corr ? d_bch_corr : h->d_corr; h->stream = stream;
-    return dvbs2_bch_decode_device(h->bch, h->d_bits, n_frames, d_msg, h->d_bch_corr, stream);
+    return chain_bch(h);
 }
 
 extern "C" {
@@ -677,8 +688,13 @@ int dvbs2_chain_enqueue_device(dvbs2_chain_t* h, const float* d_syms, int n_fram
     if (n_frames > h->max_frames) return fail(DVBS2_ESIZE, "n_frames exceeds max_frames");
     if (n_frames < 0 || max_trials <= 0 || (n_frames && !d_msg)) return fail(DVBS2_EINVAL, "bad argument");
     if (n_frames == 0) return DVBS2_OK;
+    if (!d_syms || !d_n0 || (n0_count != 1 && n0_count != n_frames)) return fail(DVBS2_EINVAL, "bad argument");
+    if (h->ldpc->dec->fused_demap_supported()) { // symbols -> LDS inside the LDPC sweep kernel: no demapper launch, no LLR buffer
+        const DemapFused dm = h->dm->dm->fused(d_syms, d_n0, n0_count);
+        return chain_enqueue_tail(h, nullptr, &dm, n_frames, max_trials, d_msg, d_ldpc_ret, d_bch_corr, stream);
+    }
     int rc = dvbs2_demap_soft_device(h->dm, d_syms, n_frames, d_n0, n0_count, h->d_llr, stream);
-    if (rc == DVBS2_OK) rc = chain_enqueue_tail(h, h->d_llr, n_frames, max_trials, d_msg, d_ldpc_ret, d_bch_corr, stream);
+    if (rc == DVBS2_OK) rc = chain_enqueue_tail(h, h->d_llr, nullptr, n_frames, max_trials, d_msg, d_ldpc_ret, d_bch_corr, stream);
     return rc;
     API_CATCH
 }
@@ -692,7 +708,7 @@ int dvbs2_chain_enqueue_llr_device(dvbs2_chain_t* h, const int8_t* d_llr, int n_
     if (n_frames > h->max_frames) return fail(DVBS2_ESIZE, "n_frames exceeds max_frames");
     if (n_frames < 0 || max_trials <= 0 || (n_frames && (!d_llr || !d_msg))) return fail(DVBS2_EINVAL, "bad argument");
     if (n_frames == 0) return DVBS2_OK;
-    return chain_enqueue_tail(h, d_llr, n_frames, max_trials, d_msg, d_ldpc_ret, d_bch_corr, stream);
+    return chain_enqueue_tail(h, d_llr, nullptr, n_frames, max_trials, d_msg, d_ldpc_ret, d_bch_corr, stream);
     API_CATCH
 }
 
@@ -713,7 +729,7 @@ int dvbs2_chain_finish(dvbs2_chain_t* h)
     const int r = h->ldpc->dec->finish(0); // waits for the stream: demapper, LDPC and BCH of this call are done
     if (r < 0) return fail(DVBS2_EDEVICE, h->ldpc->dec->error());
     if (r > 0) { // the LDPC needed rounds beyond the enqueued ones and rewrote its output: run the BCH stage again
-        int rc = dvbs2_bch_decode_device(h->bch, h->d_bits, h->n_frames, h->d_msg, h->d_bch_corr, h->stream);
+        int rc = chain_bch(h);
         if (rc != DVBS2_OK) return rc;
         HCHK(hipStreamSynchronize((hipStream_t)h->stream));
     }

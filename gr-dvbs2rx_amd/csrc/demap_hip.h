@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <string>
+#include "demap_math.hpp"
 
 namespace dvbs2 {
 
@@ -27,6 +28,8 @@ public:
     // order differs from the reference's sequential / VOLK accumulation -> tolerance only.
     // d_ref_llr != nullptr: post-decoder refinement against the decoded LLRs (:246-317)
     int snr_device(const float* d_syms, const int8_t* d_ref_llr, int n_frames, float* d_snr, hipStream_t stream);
+    // what an LDPC sweep kernel needs to do this demapper's work while it loads its frames (same arithmetic: demap_math.hpp)
+    DemapFused fused(const float* d_syms, const float* d_n0, int n0_count) const;
 
 private:
     int n_llr_ = 0, n_mod_ = 0, order_ = 0, constellation_ = 0, max_frames_ = 0, device_ = 0;

@@ -7,59 +7,52 @@
 //   8PSK  lib/psk.hh:143-150 with quantize :123-131 and rot :113; precision = (float)(4.0 / N0)
 //         (lib/xfecframe_demapper_cb_impl.cc:148); column de-interleave :162-176.
 #include "demap_hip.h"
+#include "demap_math.hpp"
 #include <cmath>
 #include "../../include/dvbs2_fec_hip.h"
 
 #include "device_guard.h"
 namespace dvbs2 {
 
-__device__ __forceinline__ int8_t sat8_rint(float v)
-{
-    if (v > 127.0f) return 127;
-    if (v < -128.0f) return -128;
-    return (int8_t)rintf(v);
-}
-
 __global__ void demap_qpsk_kernel(const float4* __restrict__ syms, const float* __restrict__ n0, int n0_count,
                                   uint32_t* __restrict__ out, int quads_per_frame, int n_frames)
 {
     const int f = blockIdx.y;
     const float N0 = n0[n0_count > 1 ? f : 0];
-    const float scalar = (float)(2.0 * 1.41421356237309504880 / (double)N0);
+    const float scalar = qpsk_scalar(N0);
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < quads_per_frame; i += gridDim.x * blockDim.x) {
         const float4 v = syms[(size_t)f * quads_per_frame + i]; // two symbols
-        const uint32_t b0 = (uint8_t)sat8_rint(__fmul_rn(v.x, scalar)), b1 = (uint8_t)sat8_rint(__fmul_rn(v.y, scalar));
-        const uint32_t b2 = (uint8_t)sat8_rint(__fmul_rn(v.z, scalar)), b3 = (uint8_t)sat8_rint(__fmul_rn(v.w, scalar));
+        const uint32_t b0 = (uint8_t)qpsk_llr(v.x, scalar), b1 = (uint8_t)qpsk_llr(v.y, scalar);
+        const uint32_t b2 = (uint8_t)qpsk_llr(v.z, scalar), b3 = (uint8_t)qpsk_llr(v.w, scalar);
         out[(size_t)f * quads_per_frame + i] = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
     }
 }
 
-__device__ __forceinline__ int8_t quant8(float dist_prec, float value)
-{
-    value = __fmul_rn(value, dist_prec);
-    value = rintf(value);
-    value = fminf(fmaxf(value, -128.0f), 127.0f);
-    return (int8_t)value;
-}
-
-__global__ void demap_8psk_kernel(const float2* __restrict__ syms, const float* __restrict__ n0, int n0_count,
-                                  int8_t* __restrict__ out, int n_syms, int ra0, int ra1, int ra2, float rr, float ri)
+// One thread per FOUR consecutive symbols: two 16-byte loads, and one dword store into each of the three de-interleaved
+// columns (rows = n_syms is a multiple of 4 for every frame size, so the column bases are dword aligned). One thread per
+// symbol with three byte stores reached 3.9 TB/s of algorithmic bytes; a wave now stores 256 contiguous bytes per instruction.
+__global__ void demap_8psk_kernel(const float4* __restrict__ syms, const float* __restrict__ n0, int n0_count,
+                                  uint32_t* __restrict__ out, int n_quads, int ra0, int ra1, int ra2, float rr, float ri)
 {
     const int f = blockIdx.y;
     const float N0 = n0[n0_count > 1 ? f : 0];
-    const float precision = (float)(4.0 / (double)N0);
-    const float sin_pi_8 = 0.38268343236508977173f;
-    const float DIST = 2 * sin_pi_8;
-    const float dp = __fmul_rn(DIST, precision);
-    const float rcp_sqrt_2 = 0.70710678118654752440f;
-    int8_t* o = out + (size_t)f * 3 * n_syms;
-    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n_syms; j += gridDim.x * blockDim.x) {
-        const float2 c = syms[(size_t)f * n_syms + j];
-        const float cr = __fsub_rn(__fmul_rn(c.x, rr), __fmul_rn(c.y, ri));
-        const float ci = __fadd_rn(__fmul_rn(c.x, ri), __fmul_rn(c.y, rr));
-        o[ra1 + j] = quant8(dp, cr);
-        o[ra2 + j] = quant8(dp, ci);
-        o[ra0 + j] = quant8(dp, __fmul_rn(rcp_sqrt_2, __fsub_rn(fabsf(cr), fabsf(ci))));
+    const float dp = psk8_dist_prec(N0);
+    uint32_t* o = out + (size_t)f * 3 * n_quads; // 3 * n_syms bytes per frame
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n_quads; j += gridDim.x * blockDim.x) {
+        const float4 a = syms[((size_t)f * n_quads + j) * 2], b = syms[((size_t)f * n_quads + j) * 2 + 1];
+        const float re[4] = { a.x, a.z, b.x, b.z }, im[4] = { a.y, a.w, b.y, b.w };
+        uint32_t w0 = 0, w1 = 0, w2 = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            int8_t b0, b1, b2;
+            psk8_llr(re[k], im[k], rr, ri, dp, b0, b1, b2);
+            w0 |= (uint32_t)(uint8_t)b0 << (8 * k);
+            w1 |= (uint32_t)(uint8_t)b1 << (8 * k);
+            w2 |= (uint32_t)(uint8_t)b2 << (8 * k);
+        }
+        o[ra1 / 4 + j] = w1;
+        o[ra2 / 4 + j] = w2;
+        o[ra0 / 4 + j] = w0;
     }
 }
 
@@ -137,12 +130,26 @@ int DemapperHip::soft_device(const float* d_syms, int n_frames, const float* d_n
         if (order_ == 1) { ra0 = 2 * rows; ra1 = rows; ra2 = 0; }
         else if (order_ == 2) { ra0 = rows; ra1 = 0; ra2 = 2 * rows; }
         const float rr = (float)std::cos(-M_PI / 8), ri = (float)std::sin(-M_PI / 8); // (complexf) exp(-j pi/8)
-        hipLaunchKernelGGL(demap_8psk_kernel, dim3((rows + 255) / 256, n_frames), dim3(256), 0, stream,
-                           reinterpret_cast<const float2*>(d_syms), d_n0, n0_count, d_llr, rows, ra0, ra1, ra2, rr, ri);
+        const int quads = rows / 4; // 21600, 10800, 5400 symbols: a multiple of 4
+        hipLaunchKernelGGL(demap_8psk_kernel, dim3((quads + 255) / 256, n_frames), dim3(256), 0, stream,
+                           reinterpret_cast<const float4*>(d_syms), d_n0, n0_count, reinterpret_cast<uint32_t*>(d_llr), quads, ra0, ra1, ra2, rr, ri);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { call_err_ = std::string("demap kernel launch: ") + hipGetErrorString(e); return -1; }
     return 0;
+}
+
+DemapFused DemapperHip::fused(const float* d_syms, const float* d_n0, int n0_count) const
+{
+    DemapFused d{};
+    d.syms = d_syms; d.n0 = d_n0; d.n0_count = n0_count; d.n_syms = n_syms();
+    d.mode = constellation_ == DVBS2_MOD_QPSK ? 1 : 2;
+    const int rows = n_syms();
+    d.ra0 = 0; d.ra1 = rows; d.ra2 = 2 * rows;
+    if (order_ == 1) { d.ra0 = 2 * rows; d.ra1 = rows; d.ra2 = 0; }
+    else if (order_ == 2) { d.ra0 = rows; d.ra1 = 0; d.ra2 = 2 * rows; }
+    d.rr = (float)std::cos(-M_PI / 8); d.ri = (float)std::sin(-M_PI / 8);
+    return d;
 }
 
 int DemapperHip::snr_device(const float* d_syms, const int8_t* d_ref_llr, int n_frames, float* d_snr, hipStream_t stream)

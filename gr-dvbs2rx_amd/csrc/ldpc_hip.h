@@ -4,6 +4,7 @@
 #include <cstdint>
 #include <string>
 #include "ldpc_schedule.h"
+#include "demap_math.hpp"
 
 namespace dvbs2 {
 
@@ -44,8 +45,14 @@ public:
     // decode_device() = enqueue() + finish().
     static constexpr int kResolveRounds = 2;
     static constexpr int kSlots = 4;
+    // dm (optional): take XFECFRAME symbols instead of LLRs and demap while the frames are loaded (d_llr_in is ignored then);
+    // only the classic sweep kernels do that (fused_demap_supported()). d_bits_out may be null when neither packed bits nor
+    // decoded LLRs are wanted (the chain's BCH stage reads the decoder state directly: state(), state_stride()).
     int enqueue(const int8_t* d_llr_in, int n_frames, int max_trials, int out_mode, uint8_t* d_bits_out, int8_t* d_llr_out,
-                int32_t* d_ret, hipStream_t stream, int slot = 0, int frame_base = 0);
+                int32_t* d_ret, hipStream_t stream, int slot = 0, int frame_base = 0, const DemapFused* dm = nullptr);
+    bool fused_demap_supported() const { return !pr_; }
+    const uint8_t* state() const { return d_state_; } // per frame N offset-binary LLR bytes, information part in natural order
+
     int finish(int slot = 0); // 0 = done, 1 = done and the outputs were rewritten by extra rounds, -1 = error
     int decode_device(const int8_t* d_llr_in, int n_frames, int max_trials, int out_mode,
                       uint8_t* d_bits_out, int8_t* d_llr_out, int32_t* d_ret, hipStream_t stream);
@@ -63,8 +70,13 @@ private:
     int words_per_check_ = 0; // message dwords per check (4 int8 messages per dword)
     int dmax_ = 0;            // kernel variant: handles check degrees dmax-7 .. dmax (8, 12, ..., 32)
     uint32_t* d_recs_ = nullptr;  // per-layer records (ldpc_hip.hip)
+    uint32_t* d_wrecs_ = nullptr; // per-(layer, wave) sweep records of the classic kernel
     size_t lds_bytes_ = 0;
     std::string kname_;
+    bool v2_ = false;             // the build with the packed nodes (check_node_v2 / check_node_chain_v2)
+    bool soft_bar_ = false;       // per-frame software barriers (high-degree tables without hazard layers)
+    bool solo_ = false;           // one frame per workgroup, complementary wave roles per CU (ldpc_kernel.hpp)
+    int* d_cu_slots_ = nullptr;   // per-CU pattern counters of the solo kernels
     bool dense_ = false;          // 80-VGPR build of the classic kernel selected (two workgroups per CU)
     bool pr_ = false;             // parity-in-records kernel variant selected (ldpc_kernel_pr.hpp)
     unsigned long long* d_tdbg_ = nullptr; // DVBS2_TIMING=1: per-wave cycle-counter breakdown (diagnostics)
@@ -79,7 +91,7 @@ private:
                      uint8_t* bits = nullptr; int8_t* llr_out = nullptr; int32_t* ret = nullptr; hipStream_t stream = nullptr; };
     Pending pend_[kSlots];
     int resolve_rounds_ = kResolveRounds;
-    void launch_sweep(const int8_t* in, bool resume, int stop_on_good, int n_frames, int max_trials, int frame_base, hipStream_t stream);
+    void launch_sweep(const int8_t* in, bool resume, int stop_on_good, int n_frames, int max_trials, int frame_base, hipStream_t stream, const DemapFused* dm = nullptr);
     void launch_targets(int n_frames, int max_trials, int frame_base, int32_t* d_ret, int slot, hipStream_t stream);
     void launch_finalize(const Pending& p);
     bool profiling_ = false;

@@ -22,6 +22,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 namespace dvbs2 {
@@ -72,7 +73,7 @@ __global__ void ldpc_finalize_kernel(const uint8_t* state, uint8_t* bits, int8_t
         if (v < 0x80u) byte |= 1u << (7 - k);
         if (llr_out) llr_out[(size_t)f * N + n] = (int8_t)(v ^ 0x80u);
     }
-    if (b < out_bytes) bits[(size_t)f * out_bytes + b] = (uint8_t)byte;
+    if (bits && b < out_bytes) bits[(size_t)f * out_bytes + b] = (uint8_t)byte;
 }
 
 LdpcDecoderHip::LdpcDecoderHip(const LdpcTableDesc* table, int out_bits_message, int group_size, int max_frames, int device)
@@ -143,6 +144,102 @@ LdpcDecoderHip::LdpcDecoderHip(const LdpcTableDesc* table, int out_bits_message,
     }
     HIP_OK(hipMalloc(&d_recs_, hr.size() * 4));
     HIP_OK(hipMemcpy(d_recs_, hr.data(), hr.size() * 4, hipMemcpyHostToDevice));
+    // Short frames whose layers are mostly hazard layers (latency-bound ordered steps) and whose degree rules out the
+    // parity-in-records kernel: the 80-VGPR build puts a second workgroup on the CU (measured: short 3/5 and 2/3 +34 %;
+    // it costs 6-18 % where regular layers dominate, hence the 70 % threshold; degree classes above 12 do not fit 80 VGPRs). DVBS2_DENSE=0 / 1 overrides.
+    dense_ = !pr_ && sched_.N < 64800 && dmax_ == 12 && 10 * sched_.conflict_layers >= 7 * sched_.q &&
+             4 * half_lds_bytes(sched_.N) <= 160 * 1024;
+    if (const char* e = getenv("DVBS2_DENSE")) dense_ = !pr_ && dmax_ == 12 && atoi(e) != 0 && 4 * half_lds_bytes(sched_.N) <= 160 * 1024;
+    // Sweep records per (layer, wave) for the classic kernel (check_node_v2 in ldpc_kernel.hpp). A regular layer i > 0 gets,
+    // for each of the six waves of a frame, its data entries reordered "mixed first" (mixed = the wrap point 360 - rot lies
+    // inside the wave's rows), window offsets pre-adjusted for the wave, and the lane masks of the mixed entries; a wave
+    // with more mixed entries than fix slots, layer 0 and hazard layers keep the classic record (replicated).
+    // Which build of the sweep kernel: measured per table (ldpc_policy.inc <- tools/policy_sweep.py + tools/gen_policy.py); a table
+    // that is not listed takes the plain pair kernel. DVBS2_V2 / DVBS2_SOLO override (tests run every build on every table).
+    bool pol_packed = false, pol_solo = false;
+    {
+        struct Pol { const char* table; int packed, solo; };
+        static const Pol kPolicy[] = {
+#include "ldpc_policy.inc"
+        };
+        for (const Pol& p : kPolicy) if (!strcmp(p.table, table->name)) { pol_packed = p.packed; pol_solo = p.solo; }
+    }
+    bool v2 = !pr_ && !dense_ && pol_packed; // (the 80-VGPR build has no packed nodes)
+    if (const char* e = getenv("DVBS2_V2")) v2 = !pr_ && !dense_ && atoi(e) != 0;
+    v2_ = v2;
+    const int RSW = rec_stride_wave(dmax_);
+    std::vector<uint32_t> wr((size_t)sched_.q * 6 * RSW, 0);
+    // single-pair hazard layers walked by the packed register chain (check_node_chain_v2): block <= kChainMaxBlock, the pair are
+    // the first two entries (schedule compiler), and on every wave the mixed regular entries fit the fix slots after the pair's
+    std::vector<char> chain_v2_layer(sched_.q, 0), chain_order(sched_.q, 0);
+    bool chain_v2 = v2 && dmax_ <= 16; // the packed chain node is only built for the low degree classes
+    if (const char* e = getenv("DVBS2_CHAIN_V2")) chain_v2 = chain_v2 && atoi(e) != 0;
+    for (int i = 1; chain_v2 && i < sched_.q; i++) {
+        const LdpcLayer& L = sched_.layers[i];
+        if (L.block >= 360 || L.block > kChainMaxBlock || L.n_conflict != 2 || L.cnt < 2) continue;
+        const LdpcEntry& a = sched_.entries[L.entry_off], & b = sched_.entries[L.entry_off + 1];
+        if (a.base != b.base) continue;
+        const int D = ((int)a.rot - (int)b.rot + 360) % 360; // X's bit of row r is Y's bit of row r + block  <=>  (rotX - rotY) mod 360 == block
+        if (D == L.block) chain_order[i] = 0; else if (360 - D == L.block) chain_order[i] = 1; else continue;
+        bool fits = true;
+        for (int w = 0; w < 6; w++) {
+            const int lo = 64 * w, hi = std::min(64 * w + 63, 359);
+            int nm = 0;
+            for (int k = 2; k < L.cnt; k++) { const int thr = 360 - (int)sched_.entries[L.entry_off + k].rot; nm += lo < thr && thr <= hi; }
+            if (nm > dmax_ / 4) fits = false;
+        }
+        chain_v2_layer[i] = fits;
+        if (const char* e = getenv("DVBS2_CHAIN_ONLY")) if (atoi(e) != i) chain_v2_layer[i] = 0; // debugging: one layer only
+    }
+    for (int i = 0; i < sched_.q; i++) {
+        const LdpcLayer& L = sched_.layers[i];
+        for (int w = 0; w < 6; w++) {
+            uint32_t* rec = &wr[((size_t)i * 6 + w) * RSW];
+            std::copy(hr.begin() + (size_t)i * RS, hr.begin() + (size_t)(i + 1) * RS, rec);
+            if (!v2 || i == 0) continue;
+            const bool chain2 = L.block < 360 && chain_v2_layer[i];
+            if (L.block < 360 && !chain2) continue;
+            const int lo = 64 * w, hi = std::min(64 * w + 63, 359);
+            std::vector<int> mixed, plain;
+            auto is_mixed = [&](int k) { const int thr = 360 - (int)sched_.entries[L.entry_off + k].rot; return lo < thr && thr <= hi; };
+            for (int k = chain2 ? 2 : 0; k < L.cnt; k++) (is_mixed(k) ? mixed : plain).push_back(k);
+            const int nfix = std::min(dmax_ / 4, (int)L.cnt);
+            if (!chain2 && (int)mixed.size() > nfix) continue; // (a chain layer was checked for every wave beforehand)
+            std::fill(rec + 4, rec + RSW, 0u);
+            rec[0] = hr[(size_t)i * RS] | (1u << 13);
+            int slot = 0;
+            auto put = [&](int k, bool is_mixed) {
+                const LdpcEntry& e = sched_.entries[L.entry_off + k];
+                const int thr = 360 - (int)e.rot;
+                const uint32_t S0 = (uint32_t)e.base + e.rot;
+                uint32_t off = S0;                       // every row of the wave below the wrap point
+                if (is_mixed || lo >= thr) off = S0 - 360u; // wrapped (mixed: the lanes below the wrap point get + 360 back)
+                rec[4 + slot] = off;
+                if (is_mixed) {
+                    unsigned long long m = 0;
+                    for (int l = 0; l < 64; l++) if (std::min(lo + l, 359) < thr) m |= 1ull << l; // threads 360..383 mirror row 359
+                    rec[4 + dmax_ + 2 * slot] = (uint32_t)m; rec[4 + dmax_ + 2 * slot + 1] = (uint32_t)(m >> 32);
+                }
+                slot++;
+            };
+            if (chain2) { // the pair X, Y (host-ordered: hr already holds them in chain order) takes the first two fix slots
+                const int kx = chain_order[i] ? 1 : 0;
+                put(kx, is_mixed(kx)); put(1 - kx, is_mixed(1 - kx));
+            }
+            for (int k : mixed) put(k, true);
+            for (int k : plain) put(k, false);
+            put(L.cnt, false);     // own parity (rot 0)
+            put(L.cnt + 1, false); // previous parity (rot 0 for i > 0)
+        }
+    }
+    // word 1 of a record: message format of the NEXT layer for the same wave (the sweep loads messages one layer ahead)
+    for (int i = 0; i + 1 < sched_.q; i++)
+        for (int w = 0; w < 6; w++) {
+            const uint32_t nh = wr[((size_t)(i + 1) * 6 + w) * RSW];
+            wr[((size_t)i * 6 + w) * RSW + 1] = ((nh & 0xffu) + 2u) | (((nh >> 13) & 1u) << 8);
+        }
+    HIP_OK(hipMalloc(&d_wrecs_, wr.size() * 4));
+    HIP_OK(hipMemcpy(d_wrecs_, wr.data(), wr.size() * 4, hipMemcpyHostToDevice));
     HIP_OK(hipMalloc(&d_state_, (size_t)max_frames_ * sched_.N));
     HIP_OK(hipMalloc(&d_msgs_, (size_t)max_frames_ * sched_.q * words_per_check_ * kMsgStride * 4));
     HIP_OK(hipMalloc(&d_iters_, (size_t)max_frames_ * 4));
@@ -153,45 +250,48 @@ LdpcDecoderHip::LdpcDecoderHip(const LdpcTableDesc* table, int out_bits_message,
     HIP_OK(hipHostMalloc(&h_flag_, 4 * kSlots));
     HIP_OK(hipEventCreate(&ev0_));
     HIP_OK(hipEventCreate(&ev1_));
-    if (getenv("DVBS2_TIMING")) { HIP_OK(hipMalloc(&d_tdbg_, (size_t)max_frames_ * 6 * 8 * 8)); HIP_OK(hipMemset(d_tdbg_, 0, (size_t)max_frames_ * 6 * 8 * 8)); }
-    // Short frames whose layers are mostly hazard layers (latency-bound ordered steps) and whose degree rules out the
-    // parity-in-records kernel: the 80-VGPR build puts a second workgroup on the CU (measured: short 3/5 and 2/3 +34 %;
-    // it costs 6-18 % where regular layers dominate, hence the 70 % threshold; degree classes above 12 do not fit 80 VGPRs). DVBS2_DENSE=0 / 1 overrides.
-    dense_ = !pr_ && sched_.N < 64800 && dmax_ == 12 && 10 * sched_.conflict_layers >= 7 * sched_.q &&
-             4 * half_lds_bytes(sched_.N) <= 160 * 1024;
-    if (const char* e = getenv("DVBS2_DENSE")) dense_ = !pr_ && dmax_ == 12 && atoi(e) != 0 && 4 * half_lds_bytes(sched_.N) <= 160 * 1024;
-    kname_ = pr_ ? std::string("ldpc_layered_pr_kernel") : "ldpc_layered_kernel<" + std::to_string(dmax_) + (dense_ ? ", dense>" : ">");
+    if (getenv("DVBS2_TIMING")) { HIP_OK(hipMalloc(&d_tdbg_, ((size_t)max_frames_ * 48 + 512) * 8)); HIP_OK(hipMemset(d_tdbg_, 0, ((size_t)max_frames_ * 48 + 512) * 8)); }
+    solo_ = !pr_ && !dense_ && dmax_ <= 16 && pol_solo;
+    if (const char* e = getenv("DVBS2_SOLO")) solo_ = !pr_ && !dense_ && dmax_ <= 16 && atoi(e) != 0;
+    if (d_tdbg_) solo_ = false;
+    soft_bar_ = !pr_ && !dense_ && !solo_ && dmax_ >= 20 && sched_.conflict_layers == 0; // frame barriers in software (ldpc_kernel.hpp)
+    if (const char* e = getenv("DVBS2_SOFT_BARRIER")) soft_bar_ = !pr_ && !dense_ && !solo_ && atoi(e) != 0;
+    if (solo_) { HIP_OK(hipMalloc(&d_cu_slots_, kCuSlots * 4)); HIP_OK(hipMemset(d_cu_slots_, 0, kCuSlots * 4)); }
+    kname_ = pr_ ? std::string("ldpc_layered_pr_kernel") : "ldpc_layered_kernel<" + std::to_string(dmax_) + (dense_ ? ", dense>" : solo_ ? (v2_ ? ", packed, solo>" : ", solo>") : (v2_ ? ", packed>" : ">"));
     lds_bytes_ = pr_ ? pr_lds_bytes(sched_.N, sched_.K) : 2 * half_lds_bytes(sched_.N);
     if (const char* e = getenv("DVBS2_LDS_PAD")) lds_bytes_ += (size_t)atoi(e); // occupancy experiments only
     if (pr_) HIP_OK(ldpc_pr_prepare(lds_bytes_));
     else switch (dmax_) {
-        case 8: HIP_OK(ldpc_variant_prepare<8>(lds_bytes_)); break;   case 12: HIP_OK(ldpc_variant_prepare<12>(lds_bytes_)); break;
-        case 16: HIP_OK(ldpc_variant_prepare<16>(lds_bytes_)); break; case 20: HIP_OK(ldpc_variant_prepare<20>(lds_bytes_)); break;
-        case 24: HIP_OK(ldpc_variant_prepare<24>(lds_bytes_)); break; case 28: HIP_OK(ldpc_variant_prepare<28>(lds_bytes_)); break;
-        case 32: HIP_OK(ldpc_variant_prepare<32>(lds_bytes_)); break;
+        case 8: HIP_OK(ldpc_variant_prepare<8>(2 * half_lds_bytes(sched_.N), half_lds_bytes(sched_.N))); break;   case 12: HIP_OK(ldpc_variant_prepare<12>(2 * half_lds_bytes(sched_.N), half_lds_bytes(sched_.N))); break;
+        case 16: HIP_OK(ldpc_variant_prepare<16>(2 * half_lds_bytes(sched_.N), half_lds_bytes(sched_.N))); break; case 20: HIP_OK(ldpc_variant_prepare<20>(2 * half_lds_bytes(sched_.N), half_lds_bytes(sched_.N))); break;
+        case 24: HIP_OK(ldpc_variant_prepare<24>(2 * half_lds_bytes(sched_.N), half_lds_bytes(sched_.N))); break; case 28: HIP_OK(ldpc_variant_prepare<28>(2 * half_lds_bytes(sched_.N), half_lds_bytes(sched_.N))); break;
+        case 32: HIP_OK(ldpc_variant_prepare<32>(2 * half_lds_bytes(sched_.N), half_lds_bytes(sched_.N))); break;
     }
 }
 
 LdpcDecoderHip::~LdpcDecoderHip()
 {
     (void)hipSetDevice(device_);
-    (void)hipFree(d_recs_); (void)hipFree(d_state_); (void)hipFree(d_msgs_);
+    (void)hipFree(d_recs_); (void)hipFree(d_wrecs_); (void)hipFree(d_cu_slots_); (void)hipFree(d_state_); (void)hipFree(d_msgs_);
     (void)hipFree(d_iters_); (void)hipFree(d_good_); (void)hipFree(d_target_); (void)hipFree(d_flag_);
     if (h_flag_) (void)hipHostFree(h_flag_);
     if (ev0_) (void)hipEventDestroy(ev0_);
     if (ev1_) (void)hipEventDestroy(ev1_);
 }
 
-void LdpcDecoderHip::launch_sweep(const int8_t* in, bool resume, int stop_on_good, int n_frames, int max_trials, int frame_base, hipStream_t stream)
+void LdpcDecoderHip::launch_sweep(const int8_t* in, bool resume, int stop_on_good, int n_frames, int max_trials, int frame_base, hipStream_t stream, const DemapFused* dm)
 {
     if (profiling_) (void)hipEventRecord(ev0_, stream);
     const size_t fb = (size_t)frame_base;
     LdpcLaunch la;
-    la.recs = d_recs_; la.llr_in = in; la.state = d_state_ + fb * sched_.N;
+    la.recs = d_recs_; la.wrecs = d_wrecs_; la.llr_in = in; la.state = d_state_ + fb * sched_.N;
     la.msgs = d_msgs_ + fb * sched_.q * words_per_check_ * kMsgStride;
     la.iters = d_iters_ + fb; la.good = d_good_ + fb; la.target = resume ? d_target_ + fb : nullptr;
-    la.n_frames = n_frames; la.N = sched_.N; la.K = sched_.K; la.q = sched_.q; la.cap = max_trials; la.stop_on_good = stop_on_good;
-    la.tdbg = d_tdbg_; la.lds_bytes = lds_bytes_; la.stream = stream; la.dense = dense_;
+    la.n_frames = n_frames; la.N = sched_.N; la.K = sched_.K; la.q = sched_.q; la.cap = max_trials; la.stop_on_good = stop_on_good | (soft_bar_ ? 2 : 0);
+    la.tdbg = d_tdbg_; la.lds_bytes = solo_ ? half_lds_bytes(sched_.N) : lds_bytes_; la.stream = stream; la.dense = dense_;
+    la.v2 = v2_; la.solo = solo_; la.cu_slots = d_cu_slots_;
+    la.dm = DemapFused{};
+    if (dm && !resume) la.dm = *dm;
     if (pr_) ldpc_pr_launch(la);
     else switch (dmax_) {
         case 8: ldpc_variant_launch<8>(la); break;   case 12: ldpc_variant_launch<12>(la); break;
@@ -217,13 +317,14 @@ void LdpcDecoderHip::launch_targets(int n_frames, int max_trials, int frame_base
 
 void LdpcDecoderHip::launch_finalize(const Pending& p)
 {
+    if (!p.bits && !p.llr_out) return; // nobody asked for packed bits or LLRs (chain: the BCH stage reads the state)
     const int out_bytes = (p.out_mode ? out_bits_message_ : sched_.N) / 8;
     hipLaunchKernelGGL(ldpc_finalize_kernel, dim3((sched_.N / 8 + 255) / 256, p.n_frames), dim3(256), 0, p.stream,
                        d_state_ + (size_t)p.frame_base * sched_.N, p.bits, p.llr_out, sched_.N, sched_.K, sched_.q, out_bytes);
 }
 
 int LdpcDecoderHip::enqueue(const int8_t* d_llr_in, int n_frames, int max_trials, int out_mode, uint8_t* d_bits_out, int8_t* d_llr_out,
-                            int32_t* d_ret, hipStream_t stream, int slot, int frame_base)
+                            int32_t* d_ret, hipStream_t stream, int slot, int frame_base, const DemapFused* dm)
 {
     if (!ok()) return -1;
     call_err_.clear();
@@ -239,9 +340,16 @@ int LdpcDecoderHip::enqueue(const int8_t* d_llr_in, int n_frames, int max_trials
     if (n_frames == 0) return 0;
     DeviceGuard dev_guard(device_);
     if (!dev_guard.ok) { p.active = false; call_err_ = "hipSetDevice failed"; return -1; }
-    launch_sweep(d_llr_in, false, 1, n_frames, max_trials, frame_base, stream);
+    if (dm && dm->mode && pr_) { p.active = false; call_err_ = "this sweep kernel does not demap while loading"; return -1; }
+    launch_sweep(d_llr_in, false, 1, n_frames, max_trials, frame_base, stream, dm);
     if (d_tdbg_) {
         HIP_RET(hipStreamSynchronize(stream));
+        if (getenv("DVBS2_TIMING_LAYERS")) { // cycles per layer of frame 0, wave 0 (sum over the sweeps so far)
+            std::vector<unsigned long long> hl(sched_.q);
+            HIP_RET(hipMemcpy(hl.data(), d_tdbg_ + (size_t)n_frames * 48, hl.size() * 8, hipMemcpyDeviceToHost));
+            HIP_RET(hipMemset(d_tdbg_ + (size_t)n_frames * 48, 0, 512 * 8));
+            for (int i = 0; i < sched_.q; i++) fprintf(stderr, "  layer %3d block %3d nconf %d deg %2d: %8.0f cycles/sweep\n", i, sched_.layers[i].block, sched_.layers[i].n_conflict, sched_.layers[i].cnt + 2, (double)hl[i] / std::max(1, max_trials));
+        }
         std::vector<unsigned long long> h((size_t)n_frames * 48);
         HIP_RET(hipMemcpy(h.data(), d_tdbg_, h.size() * 8, hipMemcpyDeviceToHost));
         double a[8] = {0};

@@ -4,6 +4,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>
+#include "demap_math.hpp"
 
 namespace dvbs2 {
 
@@ -24,10 +25,43 @@ constexpr int kSvWords = 14;        // sign-vector dwords per 360-bit group (360
 //   words 4+2k, 5+2k (k < deg): entry k as  S0 = 360*g + rot  and  thr = 360 - rot
 // Entry k addresses the LDS window [360*g, 360*g + 360) rotated by rot: check row j touches byte
 // 360*g + (j + rot) mod 360 = (j < thr ? S0 + j : S0 + j - 360).
-__host__ __device__ constexpr int rec_stride(int dmax) { return 2 * dmax + 4; }
-__host__ __device__ constexpr size_t half_lds_bytes(int N) { return ((size_t)N + (size_t)(N / kM) * kSvWords * 4 + 32 + 15) / 16 * 16; }
+__host__ __device__ constexpr int rec_stride(int dmax) { return 2 * dmax + 4; }       // per-layer records (recs)
+__host__ __device__ constexpr int rec_stride_wave(int dmax) { return 2 * dmax + 12; } // per-(layer, wave) records of the packed builds (wrecs)
+// per frame: N LLR bytes, then the sign-vector area (syndrome test; scratch of the ordered hazard phases during a sweep:
+// at least kChainScratchWords dwords, which is what short frames get instead of their small sign-vector area), then 8 flag words
+constexpr int kChainMaxBlock = 128;                                             // largest block walked as a register chain
+constexpr int kChainScratchWords = (kM + kChainMaxBlock) * 5;                   // (360 + block) x (16-byte record + 4-byte log)
+__host__ __device__ constexpr int sv_area_words(int N) { return (N / kM) * kSvWords > kChainScratchWords ? (N / kM) * kSvWords : kChainScratchWords; }
+__host__ __device__ constexpr size_t half_lds_bytes(int N) { return ((size_t)N + (size_t)sv_area_words(N) * 4 + 32 + 15) / 16 * 16; }
 
 __device__ __forceinline__ int wrap360(int t) { return t >= kM ? t - kM : t; }
+
+// experiment switches (build with -DDVBS2_OPT_x=0/1)
+#ifndef DVBS2_OPT_LDSBAR
+#define DVBS2_OPT_LDSBAR 0
+#endif
+#ifndef DVBS2_OPT_NODEPF
+#define DVBS2_OPT_NODEPF 0
+#endif
+#ifndef DVBS2_OPT_HALFBAR
+#define DVBS2_OPT_HALFBAR 0
+#endif
+// Barrier of ONE FRAME's six waves. The two frames of a workgroup share a CU only to get three waves on every SIMD
+// (2+1 / 1+2: two separate 6-wave workgroups land 4,2,3,3 -- tools/ubench/placement.hip); nothing else couples them.
+// With the hardware barrier both frames stall whenever either one is waiting for its slowest wave, for an LDS round trip
+// or for an ordered hazard step; a barrier per frame lets the other frame's waves take the idle issue slots. gfx950 has
+// no named barriers, so it is a counter in the frame's LDS region: every wave adds one (LDS executes a wave's operations
+// in order, so its earlier writes are in place when the add lands) and polls until the count reaches the expected multiple of 6.
+__device__ __forceinline__ void frame_barrier(volatile int* ctr, int& epoch, int lane)
+{
+    if (!ctr) { __syncthreads(); return; } // hardware barrier of the workgroup (the default)
+    epoch += 6;
+    asm volatile("" ::: "memory");
+    if (lane == 0) __hip_atomic_fetch_add(const_cast<int*>(ctr), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    while (*ctr - epoch < 0) __builtin_amdgcn_s_sleep(1);
+    asm volatile("" ::: "memory");
+}
+#define lds_barrier() frame_barrier(hb_ctr, hb_epoch, hb_lane)
 
 // Pinned instruction selection for the two spots where the compiler's canonical form costs more issue slots.
 // clamp(a + b + 128, 0, 255) as v_add3_u32 + v_med3_i32 (the compiler emits add, max, add, min).
@@ -195,6 +229,320 @@ __device__ __forceinline__ void check_node(uint8_t* __restrict__ lds /*the whole
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Packed check node ("v2", regular layers other than layer 0). The sweep is bound by VALU issue slots, so the node is
+// built to need fewer of them per edge:
+//   * ADDRESSES. Records are per WAVE (the host knows which 64 rows a wave owns): for an entry whose wrap point lies
+//     outside the wave's rows the window offset is pre-adjusted (S0 or S0 - 360) and the address is ONE add; the few
+//     entries whose wrap point falls inside the wave ("mixed", on average deg / 6) sit in the first NFIX slots and get
+//     + 360 on the lanes below the wrap point under an EXEC mask taken from the record (one more add). 1.3 instead of 4
+//     VALU instructions per edge.
+//   * ARITHMETIC on PAIRS of edges in the halves of one register, as value << 8 in signed 16 bit: the saturating packed
+//     add / subtract then IS the reference's int8 saturation (R1 sat8(L - m), R6 sat8(inp + out)), the message clamp (R7)
+//     is one packed max + min per pair, |inp| is packed max(d, 0 - d). A positive saturation leaves 0xff in the low
+//     byte of a half; nothing below lets it reach a result (see the notes at the uses).
+//   * MAGNITUDES are reduced in scalar form (v_min3 / v_med3 triples need fewer slots than a packed running pair), the
+//     selection "mag == min0 ? min1 : min0" is packed again: T - clamp(mag, B0, B1) with B0 = min0, B1 = B0 + (min1' -
+//     min0'), T = min1' + B0, where x' = max(x - 1, 0) (R2's offset and floor applied once per check, not per edge).
+// Messages of such a layer are two's complement bytes (this layer's records are private to it: layer 0 and hazard
+// layers keep offset binary); logical entry e = 2 j + h of pair j lives in dword j / 2, byte (j & 1) + 2 h, so that both
+// pairs of a dword unpack with one instruction each. LLR bytes in LDS stay offset binary (shared with the other paths).
+typedef short v2s16 __attribute__((ext_vector_type(2)));
+typedef unsigned short v2u16 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2s16 as_v2s(uint32_t x) { return __builtin_bit_cast(v2s16, x); }
+__device__ __forceinline__ uint32_t as_u32(v2s16 x) { return __builtin_bit_cast(uint32_t, x); }
+__device__ __forceinline__ void lds_wr_hi(int a, uint32_t v) { *reinterpret_cast<lds_byte_t*>((size_t)(uint32_t)a) = (uint8_t)(v >> 16); } // ds_write_b8_d16_hi
+
+// + 360 on the lanes of `mask` (EXEC is saved and restored: the statement is valid under any execution mask)
+__device__ __forceinline__ int fix_wrap(int ad, uint32_t mlo, uint32_t mhi)
+{
+    // (readfirstlane: a no-op for a value that already sits in an SGPR, and it keeps an SGPR that the register allocator
+    // spilled to a VGPR lane from being handed to the scalar instruction as a VGPR)
+    const unsigned long long mask = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)mhi) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)mlo);
+    unsigned long long save;
+    asm volatile("s_mov_b64 %1, exec\n\ts_and_b64 exec, exec, %2\n\tv_add_u32 %0, 0x168, %0\n\ts_mov_b64 exec, %1"
+                 : "+v"(ad), "=&s"(save) : "s"(mask) : "scc");
+    return ad;
+}
+
+constexpr int v2_nfix(int dmax) { return dmax / 4; } // fix slots per record: masks live in record words 4 + dmax + 2 k
+
+// Message storage of the packed nodes. A stored message is clamp(out, -32, 31) (R7): six bits. P6 = true keeps them as six-bit
+// two's complement fields, five per dword (entry e in word e / 5 at bit 6 (e % 5); a last word with one or two fields is a
+// 16-bit access): 4, 4, 6, 6, 8 ... bytes per check for degree 4, 5, 6, 7, 8 instead of 8. The regular layers of the
+// low-degree tables run at the bandwidth the memory system gives to this access pattern (~4.9 TB/s of message traffic on
+// table B4, whatever the node costs), so the bytes are what counts there; the unpacking costs ~2.5 VALU instructions per
+// edge, which those layers have to spare. P6 = false: one byte per message (pair j in bytes (j & 1) and (j & 1) + 2 of word j / 2).
+template <bool P6>
+__device__ __forceinline__ uint32_t msg_pair16(const uint32_t* mw, int j)
+{
+    if constexpr (P6) {
+        const int e0 = 2 * j, e1 = 2 * j + 1;
+        const int lo = __builtin_amdgcn_sbfe((int)mw[e0 / 5], 6 * (e0 % 5), 6), hi = __builtin_amdgcn_sbfe((int)mw[e1 / 5], 6 * (e1 % 5), 6);
+        return __builtin_amdgcn_perm((uint32_t)hi, (uint32_t)lo, 0x040c000cu); // [hi << 8 | lo << 8]; a field past the degree reads 0
+    } else {
+        const uint32_t w = mw[j >> 1];
+        return (j & 1) ? (w & 0xff00ff00u) : __builtin_amdgcn_perm(w, 0u, 0x060c040cu); // bytes 2, 0 of w to bytes 3, 1
+    }
+}
+template <bool P6, int NP, int NW>
+__device__ __forceinline__ void msg_pack16(const uint32_t* R /*clamped messages << 8 in both halves, pad half zero*/, uint32_t* nm)
+{
+    if constexpr (P6) {
+#pragma unroll
+        for (int w = 0; w < NW; w++) nm[w] = 0;
+#pragma unroll
+        for (int e = 0; e < 2 * NP; e++) {
+            if (e / 5 < NW) {
+                const uint32_t f = __builtin_amdgcn_ubfe(R[e >> 1], (e & 1) ? 24 : 8, 6);
+                nm[e / 5] = (e % 5) ? ((f << (6 * (e % 5))) | nm[e / 5]) : f;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int w = 0; w < (NP + 1) / 2; w++)
+            nm[w] = (2 * w + 1 < NP) ? ((R[2 * w] >> 8) | R[2 * w + 1]) : (R[2 * w] >> 8);
+    }
+}
+// words of one check's message record that hold fields, and whether word k is a 16-bit access, for degree deg
+__host__ __device__ constexpr int p6_fields(int deg, int k) { return deg - 5 * k < 0 ? 0 : (deg - 5 * k > 5 ? 5 : deg - 5 * k); }
+
+template <int DEG, int DMAX, bool P6, class Prefetch>
+__device__ __forceinline__ void check_node_v2(const uint32_t* ent /*record words 4..: S0w[DMAX], then (mask lo, mask hi)[NFIX]*/,
+                                              int jjb, const uint32_t* mw, uint32_t* nm, Prefetch prefetch_next_record)
+{
+    constexpr int NP = (DEG + 1) / 2;      // pairs
+    constexpr int NFIX = v2_nfix(DMAX) < DEG - 2 ? v2_nfix(DMAX) : DEG - 2; // parity entries never wrap
+    constexpr bool ODD = (DEG & 1) != 0;   // the upper half of the last pair is a pad: L = m = 0, magnitude "absent"
+    __builtin_amdgcn_s_setprio(0);
+    int ad[DEG];
+#pragma unroll
+    for (int k = 0; k < DEG; k++) ad[k] = jjb + (int)ent[k];
+#pragma unroll
+    for (int k = 0; k < NFIX; k++) ad[k] = fix_wrap(ad[k], ent[DMAX + 2 * k], ent[DMAX + 2 * k + 1]);
+    int Lb[DEG];
+#pragma unroll
+    for (int k = 0; k < DEG; k++) Lb[k] = lds_rd(ad[k]);
+    v2s16 d[NP], a[NP];
+    uint32_t sx = 0;
+#pragma unroll
+    for (int j = 0; j < NP; j++) {
+        const uint32_t M = msg_pair16<P6>(mw, j); // messages of pair j: << 8 in both halves
+        const uint32_t hi = (ODD && j == NP - 1) ? 0x80u : (uint32_t)Lb[2 * j + 1];
+        const uint32_t L = __builtin_amdgcn_perm(hi, (uint32_t)Lb[2 * j], 0x040c000cu) ^ 0x80008000u; // offset binary -> two's complement << 8
+        d[j] = __builtin_elementwise_sub_sat(as_v2s(L), as_v2s(M));           // R1 (a half that saturates upwards reads 0x7fff)
+        sx ^= as_u32(d[j]);                                                   // R4: bits 15 and 31 collect the signs
+        a[j] = __builtin_elementwise_max(d[j], __builtin_elementwise_sub_sat(as_v2s(0u), d[j])); // |inp| << 8 (0x7fff for -128 and for saturated halves)
+    }
+    __builtin_amdgcn_s_setprio(1);
+    // The scalar loads of the NEXT layer's record are issued HERE: scalar memory shares its counter with LDS and returns
+    // out of order, so while one is in flight every wait for an LDS read degenerates to "wait for everything"; from this
+    // point to the end of the node there are only LDS writes, and the ~100 VALU instructions that follow cover the load
+    // even when it misses the scalar cache (the per-wave records of a table no longer fit it).
+    // (the record pointer is made to depend on the xor of all inputs, so the loads cannot be placed above the last LDS wait)
+#if DVBS2_OPT_NODEPF
+    __builtin_amdgcn_sched_barrier(0);
+    prefetch_next_record(sx);
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+    int mg[DEG];
+#pragma unroll
+    for (int k = 0; k < DEG; k++) mg[k] = (k & 1) ? (int)(as_u32(a[k >> 1]) >> 16) : (int)(as_u32(a[k >> 1]) & 0xffffu);
+    int n0, n1;
+    two_smallest<DEG>(mg, n0, n1);
+    // the low byte (0xff after a saturation) is dropped HERE, once per check: every selected magnitude below is B0/B1-clamped,
+    // so a 0x7fff among the inputs can only come out as the clean 0x7f00 level it stands for
+    n0 &= 0x7f00; n1 &= 0x7f00;
+    // R2: mag = max(|inp| - 1, 0), applied to the two minima (monotone); unsigned saturating subtract (full rate)
+    const int n0m = (int)__builtin_elementwise_sub_sat((uint32_t)n0, 256u), n1m = (int)__builtin_elementwise_sub_sat((uint32_t)n1, 256u);
+    const int B0 = n0, B1 = n0 + n1m - n0m, T = n1m + n0;
+    const v2s16 B0p = { (short)B0, (short)B0 }, B1p = { (short)B1, (short)B1 }, Tp = { (short)T, (short)T };
+    const uint32_t tm = (uint32_t)((int)(sx ^ (sx << 16)) >> 31); // all ones when the number of negative inputs is odd
+    uint32_t R[NP];
+#pragma unroll
+    for (int j = 0; j < NP; j++) {
+        // R5: |out| = mag == min0 ? min1' : min0'  ==  T - clamp(|inp|, B0, B1); sign = total ^ own
+        const v2s16 c = __builtin_elementwise_min(__builtin_elementwise_max(a[j], B0p), B1p);
+        const v2s16 other = Tp - c;
+        const v2s16 sg = as_v2s(as_u32(d[j]) ^ tm) >> (v2s16){ 15, 15 };
+        const v2s16 out = as_v2s(as_u32(other) ^ as_u32(sg)) - sg;
+        // R6: LLR = sat8(inp + out); the low byte of a half never reaches the byte that is stored
+        const uint32_t nl = (as_u32(__builtin_elementwise_add_sat(d[j], out)) ^ 0x80008000u) >> 8;
+        lds_wr(ad[2 * j], (int)nl);
+        if (!(ODD && j == NP - 1)) lds_wr_hi(ad[2 * j + 1], nl);
+        // R7
+        R[j] = as_u32(__builtin_elementwise_min(__builtin_elementwise_max(out, (v2s16){ -32 * 256, -32 * 256 }), (v2s16){ 31 * 256, 31 * 256 }));
+    }
+    __builtin_amdgcn_s_setprio(3);
+    if (ODD) R[NP - 1] &= 0x0000ffffu; // the pad's message stays zero
+    msg_pack16<P6, NP, DMAX / 4>(R, nm);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Hazard layer with ONE pair (two entries X, Y of one group, block B <= kChainMaxBlock), packed arithmetic, register chain.
+// The host orders the pair so that X's bit of row r is Y's bit of row r + B: row r hands its new X value to row r + B.
+//   heads  r < B            X and Y both original                       -> Y written at once, X starts the chain
+//   middle B <= r < 360-B   X original, Y = X of row r - B (chain)
+//   tails  r >= 360 - B     X = Y of head r + B - 360 (in LDS after the heads), Y from the chain; final writer of X
+// Phases (frame barriers between them): P1 all rows: regular entries read and reduced (packed, as check_node_v2); heads also
+// resolve their pair. P2 rows >= B: read X, publish the chain operands of their row as four floats. P3 the B head lanes walk
+// r -> r + B: six VALU instructions per step on exact small integers in float (fma, two med3 with a negated operand, sub,
+// add, clamp) plus one 16-byte read and one 4-byte log write; a lone wave issues one instruction per ~4 cycles, so the step
+// costs its instruction count. P4 all rows: pair completed from the log, final minima, outputs of every entry, messages.
+// Identical to the reference's row order: a bit of the pair is touched by exactly two rows, the later one sees the earlier one.
+//   chain step for row r with incoming Y value c (offset binary 0..255):  x = sigma (c - 128 - mY),
+//   out = sgn(x) min(P, max(|x| - 1, 0)) = w - sgn(w), w = clamp(x, -(P+1), P+1);  c' = clamp(inpX + 128 + out, 0, 255)
+__device__ __forceinline__ float as_f32(uint32_t x) { return __builtin_bit_cast(float, x); }
+__device__ __forceinline__ float vmed3_f32(float a, float b, float c) { return __builtin_amdgcn_fmed3f(a, b, c); }
+__device__ __forceinline__ float byte1_f32(uint32_t x) { return (float)((x >> 8) & 0xffu); } // v_cvt_f32_ubyte1
+
+template <int DEG, int DMAX, bool P6>
+__device__ __forceinline__ void check_node_chain_v2(const uint32_t* ent /*S0w[DMAX], masks[NFIX + 2]*/, int jj, int jjb, bool work, int B,
+                                                    const uint32_t* mw, uint32_t* nm, uint32_t* tab /*LDS scratch*/,
+                                                    volatile int* hb_ctr, int& hb_epoch, const int hb_lane)
+{
+    constexpr int NP = (DEG + 1) / 2;
+    constexpr int NFIXH = (v2_nfix(DMAX) + 2) < DEG - 2 ? (v2_nfix(DMAX) + 2) : DEG - 2;
+    constexpr bool ODD = (DEG & 1) != 0;
+    constexpr bool KEEP_AD = DEG <= 16; // high degrees recompute the addresses in P4 instead of holding 30 registers across the phases
+    float4* rec = reinterpret_cast<float4*>(tab);                 // [360 + B] chain operands
+    float* logv = reinterpret_cast<float*>(tab) + 4 * (kM + kChainMaxBlock); // [360 + B] value that arrived at row r
+    const bool head = work && jj < B, body = work && jj >= B;
+    const bool middle = body && jj + B < kM; // rows whose new X value travels down the chain; the others (tails) end a chain
+    int LbX = 0x80;
+    int ad[DEG];
+    v2s16 d[NP], a[NP];
+    uint32_t sxp = 0;
+    int p0 = 0x7fff, p1 = 0x7fff;
+    int Pm = 0;
+    float c = 0.f;
+    __builtin_amdgcn_s_setprio(0);
+    auto addresses = [&]() {
+#pragma unroll
+        for (int k = 0; k < DEG; k++) ad[k] = jjb + (int)ent[k];
+#pragma unroll
+        for (int k = 0; k < NFIXH; k++) ad[k] = fix_wrap(ad[k], ent[DMAX + 2 * k], ent[DMAX + 2 * k + 1]);
+    };
+    auto pair0 = [&](int LbX, int LbY) { // d, |d| of the pair [X | Y]
+        const uint32_t L = __builtin_amdgcn_perm((uint32_t)LbY, (uint32_t)LbX, 0x040c000cu) ^ 0x80008000u;
+        const uint32_t M = msg_pair16<P6>(mw, 0);
+        d[0] = __builtin_elementwise_sub_sat(as_v2s(L), as_v2s(M));
+        a[0] = __builtin_elementwise_max(d[0], __builtin_elementwise_sub_sat(as_v2s(0u), d[0]));
+    };
+    if (work) {
+        addresses();
+        int Lb[DEG];
+#pragma unroll
+        for (int k = 2; k < DEG; k++) Lb[k] = lds_rd(ad[k]);
+        int LbY = 0x80;
+        if (head) { LbX = lds_rd(ad[0]); LbY = lds_rd(ad[1]); }
+        else if (middle) LbX = lds_rd(ad[0]); // original value: the only other row that touches this bit comes later (row jj + B)
+#pragma unroll
+        for (int j = 1; j < NP; j++) {
+            const uint32_t M = msg_pair16<P6>(mw, j);
+            const uint32_t hi = (ODD && j == NP - 1) ? 0x80u : (uint32_t)Lb[2 * j + 1];
+            const uint32_t L = __builtin_amdgcn_perm(hi, (uint32_t)Lb[2 * j], 0x040c000cu) ^ 0x80008000u;
+            d[j] = __builtin_elementwise_sub_sat(as_v2s(L), as_v2s(M));
+            sxp ^= as_u32(d[j]);
+            a[j] = __builtin_elementwise_max(d[j], __builtin_elementwise_sub_sat(as_v2s(0u), d[j]));
+        }
+        int mg[DEG - 2];
+#pragma unroll
+        for (int k = 2; k < DEG; k++) mg[k - 2] = (k & 1) ? (int)(as_u32(a[k >> 1]) >> 16) : (int)(as_u32(a[k >> 1]) & 0xffffu);
+        two_smallest<DEG - 2>(mg, p0, p1); // raw |inp| << 8 of the regular entries (a pad never enters: DEG - 2 real values)
+        Pm = (int)(__builtin_elementwise_sub_sat((uint32_t)(p0 & 0x7f00), 256u) >> 8); // R2 on the partial minimum: 0..126
+        if (head) {
+            pair0(LbX, LbY);
+            // the other entry of the pair is the only input outside the partial: |out_X| = min(Pm, mag Y) and vice versa
+            const uint32_t sw = __builtin_amdgcn_alignbit(as_u32(a[0]), as_u32(a[0]), 16) & 0x7f007f00u;
+            const v2u16 mgs = __builtin_elementwise_sub_sat(__builtin_bit_cast(v2u16, sw), (v2u16){ 256, 256 });
+            const v2s16 other = __builtin_elementwise_min(__builtin_bit_cast(v2s16, mgs), (v2s16){ (short)(Pm << 8), (short)(Pm << 8) });
+            const uint32_t par = (uint32_t)((int)(sxp ^ (sxp << 16)) >> 31);
+            const uint32_t ds = __builtin_amdgcn_alignbit(as_u32(d[0]), as_u32(d[0]), 16);
+            const v2s16 sg = as_v2s(ds ^ par) >> (v2s16){ 15, 15 };
+            const v2s16 out = as_v2s(as_u32(other) ^ as_u32(sg)) - sg;
+            const uint32_t nl = as_u32(__builtin_elementwise_add_sat(d[0], out)) ^ 0x80008000u; // offset binary in bytes 1 and 3
+            lds_wr_hi(ad[1], nl >> 8);                                 // Y now (a tail row reads it as its X)
+            c = byte1_f32(nl);                   // X starts the chain
+        }
+    }
+    // chain operands of the middle rows (a tail row only receives: the walker logs what arrives there and needs nothing from it)
+    if (middle) {
+        const uint32_t L = __builtin_amdgcn_perm(0x80u, (uint32_t)LbX, 0x040c000cu) ^ 0x80008000u;
+        const uint32_t M0 = msg_pair16<P6>(mw, 0);
+        const uint32_t M = M0 & 0x0000ffffu;
+        const v2s16 dx = __builtin_elementwise_sub_sat(as_v2s(L), as_v2s(M));       // [inp_X | 0]
+        const uint32_t fold = sxp ^ (sxp << 16);                                      // bit 31: parity of the signs of the regular entries (the inputs other than X and Y)
+        const float sigma = as_f32(0x3f800000u | (fold & 0x80000000u));
+        const int mY = (int)M0 >> 24;                                                 // Y's message (upper half of the pair, << 8)
+        float4 r;
+        r.x = sigma;
+        r.y = -sigma * (float)(128 + mY);
+        r.z = (float)(Pm + 1);
+        r.w = byte1_f32(as_u32(dx) ^ 0x8000u);                  // inp_X + 128
+        rec[jj] = r;
+    }
+    lds_barrier();
+    if (head) {
+        // rows past 359 read the padding of the table and log into the padding: no per-lane predicate in the loop
+        const float4* rp = rec + jj + B;
+        float* lp = logv + jj + B;
+        float4 r = *rp;
+        const int nsteps = (kM - 1) / B; // rows jj + k B, k = 1 .. nsteps (the last one may lie in the padding)
+        __builtin_amdgcn_s_setprio(3);
+#pragma unroll 4
+        for (int k = 0; k < nsteps; k++) {
+            const float4 rc = r;
+            rp += B;
+            r = *rp; // next row's operands, in flight during this step
+            *lp = c; lp += B;
+            const float x = __builtin_fmaf(c, rc.x, rc.y);
+            const float w = vmed3_f32(x, -rc.z, rc.z);
+            const float f = w - vmed3_f32(w, -1.f, 1.f);
+            c = vmed3_f32(rc.w + f, 0.f, 255.f);
+        }
+        __builtin_amdgcn_s_setprio(0);
+    }
+    lds_barrier();
+    if (work) {
+        if constexpr (!KEEP_AD) addresses();
+        if (body) {
+            if (!middle) LbX = lds_rd(ad[0]); // tail: the Y value its head wrote in the first phase
+            pair0(LbX, (int)logv[jj]);
+        }
+        sxp ^= as_u32(d[0]);
+        int m4[4] = { p0, p1, (int)(as_u32(a[0]) & 0xffffu), (int)(as_u32(a[0]) >> 16) };
+        int n0, n1;
+        two_smallest<4>(m4, n0, n1);
+        n0 &= 0x7f00; n1 &= 0x7f00;
+        const int n0m = (int)__builtin_elementwise_sub_sat((uint32_t)n0, 256u), n1m = (int)__builtin_elementwise_sub_sat((uint32_t)n1, 256u);
+        const int B0 = n0, B1 = n0 + n1m - n0m, T = n1m + n0;
+        const v2s16 B0p = { (short)B0, (short)B0 }, B1p = { (short)B1, (short)B1 }, Tp = { (short)T, (short)T };
+        const uint32_t tm = (uint32_t)((int)(sxp ^ (sxp << 16)) >> 31);
+        uint32_t R[NP];
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int j = 0; j < NP; j++) {
+            const v2s16 cl = __builtin_elementwise_min(__builtin_elementwise_max(a[j], B0p), B1p);
+            const v2s16 other = Tp - cl;
+            const v2s16 sg = as_v2s(as_u32(d[j]) ^ tm) >> (v2s16){ 15, 15 };
+            const v2s16 out = as_v2s(as_u32(other) ^ as_u32(sg)) - sg;
+            const uint32_t nl = (as_u32(__builtin_elementwise_add_sat(d[j], out)) ^ 0x80008000u) >> 8;
+            if (j == 0) {
+                if (jj + B >= kM) lds_wr(ad[0], (int)nl);   // a tail row is the last writer of its X bit (the others handed X down the chain)
+                if (body) lds_wr_hi(ad[1], nl);             // heads wrote Y in P1 (by now a tail row may have replaced it)
+            } else {
+                lds_wr(ad[2 * j], (int)nl);
+                if (!(ODD && j == NP - 1)) lds_wr_hi(ad[2 * j + 1], nl);
+            }
+            R[j] = as_u32(__builtin_elementwise_min(__builtin_elementwise_max(out, (v2s16){ -32 * 256, -32 * 256 }), (v2s16){ 31 * 256, 31 * 256 }));
+        }
+        __builtin_amdgcn_s_setprio(3);
+        if (ODD) R[NP - 1] &= 0x0000ffffu;
+        msg_pack16<P6, NP, DMAX / 4>(R, nm);
+    }
+}
+
 // Hazard layer (two or more entries of one group, ldpc_schedule.h): the reference's strictly ordered update
 // makes check j see what checks j' < j wrote to the bits they share. Only the NC hazard entries (placed first)
 // carry that dependency, so the check node is split in three:
@@ -215,8 +563,9 @@ constexpr int kMaxHazard = 8;
 constexpr int kHazardWalk = 15; // header code: too many hazard entries, fall back to the single-wave chunk walk
 template <int DEG, int NC, bool LAYER0, bool PR = false, bool LAST = false>
 __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, const uint32_t* ent, int jj, int lb, bool work,
-                                                  int block, const uint32_t* mw, uint32_t* nm, int own_in = 0, int* carry = nullptr,
-                                                  uint32_t* tab = nullptr /*lane_chain_words(block) of LDS scratch when the layer is a lane chain*/)
+                                                  int block, const uint32_t* mw, uint32_t* nm, int own_in, int* carry,
+                                                  uint32_t* tab /*lane_chain_words(block) of LDS scratch when the layer is a lane chain*/,
+                                                  volatile int* hb_ctr, int& hb_epoch, const int hb_lane /*frame barrier state*/)
 {
     constexpr bool OWN_REG = PR && !LAST;     // entry DEG-2 (see check_node)
     constexpr bool PREV_REG = PR && !LAYER0;  // entry DEG-1
@@ -294,14 +643,14 @@ __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, con
             chained = sat_sum_u8(inp[0], hout[0]);
             lds_wr(ad[1], sat_sum_u8(inp[1], hout[1]));
         }
-        __syncthreads();
+        lds_barrier();
         if (body) {
             const int L0 = lds_rd(ad[0]);
             inp[0] = min(max(L0 - hmb[0], -128), 127);
             mg[0] = mag_raw(L0, hmb[0]);
             tab[jj] = ((uint32_t)inp[0] & 0x1ffu) | ((uint32_t)min0 << 9) | (((uint32_t)signs >> 31) << 16) | ((uint32_t)hmb[1] << 24);
         }
-        __syncthreads();
+        lds_barrier();
         if (head) {
             // rows past 359 read the padding of the table and log into the padding: no per-lane predicate in the loop
             const uint32_t* tp = tab + jj + block;
@@ -322,7 +671,7 @@ __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, con
                 chained = sat_sum_u8(i0, (o0 ^ s0) - s0);
             }
         }
-        __syncthreads();
+        lds_barrier();
         if (body) {
             const int L1 = ulog[jj];
             inp[1] = min(max(L1 - hmb[1], -128), 127);
@@ -385,9 +734,9 @@ __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, con
         }
         // the next block reads what this one wrote: a workgroup barrier, unless both blocks sit inside one and the
         // same wavefront (LDS operations of a wave execute in program order)
-        if ((start >> 6) != ((start + 2 * block - 1) >> 6)) __syncthreads();
+        if ((start >> 6) != ((start + 2 * block - 1) >> 6)) lds_barrier();
     }
-    __syncthreads();
+    lds_barrier();
     if constexpr (NC == 2) { mg[0] = clamp_mag(mg[0]); mg[1] = clamp_mag(mg[1]); } // raw in the loop (127 where no step ran: idle rows)
 #pragma unroll
     for (int k = 0; k < NC; k++) {
@@ -426,8 +775,26 @@ __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, con
         DVBS2_DEG_CASE(27) DVBS2_DEG_CASE(28) DVBS2_DEG_CASE(29) DVBS2_DEG_CASE(30) DVBS2_DEG_CASE(31) DVBS2_DEG_CASE(32) \
         default: break; }
 
+#define DVBS2_V2_CASE(D) case D: if constexpr (D >= 3 && D <= DMAX && D > DMAX - 8) { check_node_v2<(D >= 3 ? D : 3), DMAX, P6>(ent, jj + lb, mw, nm, prefetch); } break;
+#define DVBS2_V2_SWITCH switch (deg) { \
+        DVBS2_V2_CASE(3) DVBS2_V2_CASE(4) DVBS2_V2_CASE(5) DVBS2_V2_CASE(6) DVBS2_V2_CASE(7) DVBS2_V2_CASE(8) \
+        DVBS2_V2_CASE(9) DVBS2_V2_CASE(10) DVBS2_V2_CASE(11) DVBS2_V2_CASE(12) DVBS2_V2_CASE(13) DVBS2_V2_CASE(14) \
+        DVBS2_V2_CASE(15) DVBS2_V2_CASE(16) DVBS2_V2_CASE(17) DVBS2_V2_CASE(18) DVBS2_V2_CASE(19) DVBS2_V2_CASE(20) \
+        DVBS2_V2_CASE(21) DVBS2_V2_CASE(22) DVBS2_V2_CASE(23) DVBS2_V2_CASE(24) DVBS2_V2_CASE(25) DVBS2_V2_CASE(26) \
+        DVBS2_V2_CASE(27) DVBS2_V2_CASE(28) DVBS2_V2_CASE(29) DVBS2_V2_CASE(30) DVBS2_V2_CASE(31) DVBS2_V2_CASE(32) \
+        default: break; }
+
+#define DVBS2_CHAIN_CASE(D) case D: if constexpr (D >= 4 && D <= DMAX && D > DMAX - 8) { check_node_chain_v2<(D >= 4 ? D : 4), DMAX, P6>(ent, jj, jj + lb, work, block, mw, nm, htab16, hb_ctr, hb_epoch, hb_lane); } break;
+#define DVBS2_CHAIN_SWITCH switch (deg) { \
+        DVBS2_CHAIN_CASE(4) DVBS2_CHAIN_CASE(5) DVBS2_CHAIN_CASE(6) DVBS2_CHAIN_CASE(7) DVBS2_CHAIN_CASE(8) \
+        DVBS2_CHAIN_CASE(9) DVBS2_CHAIN_CASE(10) DVBS2_CHAIN_CASE(11) DVBS2_CHAIN_CASE(12) DVBS2_CHAIN_CASE(13) DVBS2_CHAIN_CASE(14) \
+        DVBS2_CHAIN_CASE(15) DVBS2_CHAIN_CASE(16) DVBS2_CHAIN_CASE(17) DVBS2_CHAIN_CASE(18) DVBS2_CHAIN_CASE(19) DVBS2_CHAIN_CASE(20) \
+        DVBS2_CHAIN_CASE(21) DVBS2_CHAIN_CASE(22) DVBS2_CHAIN_CASE(23) DVBS2_CHAIN_CASE(24) DVBS2_CHAIN_CASE(25) DVBS2_CHAIN_CASE(26) \
+        DVBS2_CHAIN_CASE(27) DVBS2_CHAIN_CASE(28) DVBS2_CHAIN_CASE(29) DVBS2_CHAIN_CASE(30) DVBS2_CHAIN_CASE(31) DVBS2_CHAIN_CASE(32) \
+        default: break; }
+
 #define DVBS2_HAZ_CALL(D, NCV) { if constexpr (D - 2 >= NCV) { \
-        if (layer0) check_node_hazard<D, NCV, true>(lds_all, ent, jj, lb, work, block, mw, nm, 0, nullptr, htab); else check_node_hazard<D, NCV, false>(lds_all, ent, jj, lb, work, block, mw, nm, 0, nullptr, htab); } }
+        if (layer0) check_node_hazard<D, NCV, true>(lds_all, ent, jj, lb, work, block, mw, nm, 0, nullptr, htab, hb_ctr, hb_epoch, hb_lane); else check_node_hazard<D, NCV, false>(lds_all, ent, jj, lb, work, block, mw, nm, 0, nullptr, htab, hb_ctr, hb_epoch, hb_lane); } }
 #define DVBS2_HAZ_CASE(D) case D: if constexpr (D >= 4 && D <= DMAX && D > DMAX - 8) { \
         if (nc == 2) DVBS2_HAZ_CALL((D >= 4 ? D : 4), 2) else if (nc == 4) DVBS2_HAZ_CALL((D >= 4 ? D : 4), 4) else DVBS2_HAZ_CALL((D >= 4 ? D : 4), 8) } break;
 #define DVBS2_HAZ_SWITCH switch (deg) { \
@@ -440,17 +807,40 @@ __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, con
 
 // MINW = 6 ("dense"): compiled for 80 VGPRs so that two pair-workgroups share a CU when the frames are short enough for
 // LDS. It spills and only pays where ordered hazard steps dominate (ldpc_hip.hip picks it).
-template <int DMAX, bool TIMING, int MINW = 1>
-__global__ __launch_bounds__(kThreads, MINW) void ldpc_layered_kernel(
-    const uint32_t* __restrict__ recs, const int8_t* __restrict__ llr_in, uint8_t* __restrict__ state,
+// V2: the packed nodes (check_node_v2, check_node_chain_v2) are compiled in; a table runs the build that measured faster for it
+// (compiling both families into one kernel costs each of them 4-7 % through register allocation).
+// SOLO: ONE frame per workgroup, two (or more) independent workgroups per CU. The pair workgroup exists only to put three
+// waves on every SIMD; its price is that the hardware barrier couples the two frames, so each one also waits through the other's
+// ordered hazard steps, LDS round trips and stragglers. Two separate 6-wave workgroups land 4,2,3,3 on the SIMDs
+// (tools/ubench/placement.hip: waves go round the SIMDs, the next workgroup starts one position later). SOLO launches EIGHT waves
+// -- always two per SIMD -- and lets two of them leave at once: a workgroup keeps both waves on one pair of SIMDs and one
+// wave on the other pair, and workgroups sharing a CU take complementary patterns (a counter pair per CU in global memory).
+// Result: three working waves per SIMD again, but the frames no longer wait for each other. Needs <= 128 VGPRs.
+constexpr int kSoloThreads = 512;
+__device__ __forceinline__ uint32_t hw_cu_index()
+{
+    uint32_t hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    // HW_ID: simd_id[5:4] cu_id[11:8] sh_id[12] se_id[15:13]
+    return ((((xcc & 0xfu) * 8u + ((hw >> 13) & 7u)) * 2u + ((hw >> 12) & 1u)) * 16u + ((hw >> 8) & 0xfu));
+}
+constexpr int kCuSlots = 16 * 8 * 2 * 16;
+
+template <int DMAX, bool TIMING, int MINW = 1, bool V2 = false, bool SOLO = false>
+__global__ __launch_bounds__(SOLO ? kSoloThreads : kThreads, SOLO ? 4 : MINW) void ldpc_layered_kernel(
+    const uint32_t* __restrict__ recs, const uint32_t* __restrict__ wrecs /*per (layer, wave) sweep records*/,
+    const int8_t* __restrict__ llr_in, uint8_t* __restrict__ state,
     uint32_t* __restrict__ msgs, int* __restrict__ iters, int* __restrict__ good, const int* __restrict__ target,
-    int n_frames, int N, int K, int q, int cap, int stop_on_good, unsigned long long* __restrict__ tdbg)
+    int n_frames, int N, int K, int q, int cap, int stop_on_good, unsigned long long* __restrict__ tdbg, int* __restrict__ cu_slots,
+    const DemapFused dm /*mode != 0: a fresh decode takes XFECFRAME symbols and demaps while loading (llr_in is null then)*/)
 {
     unsigned long long tm_bar = 0, tm_body = 0, tm_conf = 0, tm_synd = 0, tm_sweep = 0, tm_load = 0, tm_s1 = 0;
 #define TSTAMP(x) do { if (TIMING) { x = __builtin_readcyclecounter(); } } while (0)
     unsigned long long tA = 0, tB = 0, tC = 0, tS0 = 0, tS1 = 0;
-    if (!llr_in) { // resume launch: a workgroup whose frames are both at their target leaves before touching LDS
-        const int fa = 2 * (int)blockIdx.x, fb = fa + 1;
+    const bool fresh = llr_in != nullptr || dm.mode != 0;
+    if (!fresh) { // resume launch: a workgroup whose frames are all at their target leaves before touching LDS
+        const int fa = SOLO ? (int)blockIdx.x : 2 * (int)blockIdx.x, fb = SOLO ? fa : fa + 1;
         const bool ta = fa < n_frames && iters[fa] < target[fa];
         const bool tb = fb < n_frames && iters[fb] < target[fb];
         if (!ta && !tb) return;
@@ -458,19 +848,57 @@ __global__ __launch_bounds__(kThreads, MINW) void ldpc_layered_kernel(
     TSTAMP(tA);
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_all[];
     constexpr int RS = rec_stride(DMAX);
+    constexpr int RSW = V2 ? 6 * rec_stride_wave(DMAX) : rec_stride(DMAX); // dwords from one layer's sweep record to the next
     constexpr int MW = DMAX / 4; // message dwords per check (fixed per kernel variant)
-    const int half = __builtin_amdgcn_readfirstlane(threadIdx.x >= kHalf ? 1 : 0); // wave-uniform, and the compiler knows it
-    const int tid = threadIdx.x - half * kHalf;
+    int solo_tid = (int)threadIdx.x;
+    int solo_slot = -1, solo_pat = 0;
+    if constexpr (SOLO) {
+        // role election (the first words of LDS are scratch until the LLRs are loaded)
+        volatile int* e = reinterpret_cast<volatile int*>(lds_all); // [0..3] waves seen per SIMD, [4] workers so far, [5] pattern
+        if (threadIdx.x < 8) e[threadIdx.x] = 0;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            solo_slot = (int)hw_cu_index();
+            int* w = cu_slots + solo_slot; // low half: workgroups with pattern 0 resident on this CU, high half: pattern 1
+            int old = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), pat;
+            do { pat = (old & 0xffff) <= (old >> 16) ? 0 : 1; }
+            while (!__hip_atomic_compare_exchange_strong(w, &old, old + (pat ? 0x10000 : 1), __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            e[5] = pat; e[6] = solo_slot;
+        }
+        __syncthreads();
+        solo_pat = e[5]; solo_slot = e[6];
+        int widx = -1;
+        if ((threadIdx.x & 63) == 0) {
+            uint32_t hw;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+            const int simd = (int)((hw >> 4) & 3u);
+            const int rank = __hip_atomic_fetch_add(const_cast<int*>(e) + simd, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const bool two = ((simd >> 1) & 1) == solo_pat; // pattern 0 keeps both waves on SIMDs 0,1; pattern 1 on SIMDs 2,3
+            if (two || rank == 0) widx = __hip_atomic_fetch_add(const_cast<int*>(e) + 4, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        widx = __builtin_amdgcn_readfirstlane(widx);
+        __syncthreads();
+        // a workgroup that was NOT placed two waves per SIMD elects fewer or more than six: the surplus leaves, a shortfall cannot
+        // be repaired (it has not been observed; the launch would then miss rows) -- so insist on six by falling back to arrival order
+        const int nworkers = e[4];
+        if (nworkers != 6) widx = (int)(threadIdx.x >> 6) < 6 ? (int)(threadIdx.x >> 6) : -1;
+        __syncthreads(); // everyone has read the election words; they may be overwritten now
+        if (widx < 0 || widx >= 6) return; // the two spare waves leave (the hardware barrier no longer counts them)
+        solo_tid = widx * 64 + (int)(threadIdx.x & 63);
+    }
+    const int half = SOLO ? 0 : __builtin_amdgcn_readfirstlane(threadIdx.x >= kHalf ? 1 : 0); // wave-uniform, and the compiler knows it
+    const int tid = SOLO ? solo_tid : (int)threadIdx.x - half * kHalf;
     const int lb_rel = half * (int)half_lds_bytes(N);
     const int lb = lb_rel + lds_address_of(lds_all); // absolute LDS address of this frame's region
     uint8_t* lds = lds_all + lb_rel;
     uint32_t* sv = reinterpret_cast<uint32_t*>(lds + N); // N % 8 == 0
-    volatile int* flags = reinterpret_cast<volatile int*>(sv + (N / kM) * kSvWords); // [0] bad-or, [1] finished, [2] pre-test failed, [3] full test needed
+    volatile int* flags = reinterpret_cast<volatile int*>(sv + sv_area_words(N)); // [0] bad-or, [1] finished, [2] pre-test failed, [3] full test needed
     volatile int* other_flags = reinterpret_cast<volatile int*>(
-        lds_all + (1 - half) * half_lds_bytes(N) + N + (size_t)(N / kM) * kSvWords * 4);
-    const int f = 2 * blockIdx.x + half;
+        lds_all + (1 - half) * half_lds_bytes(N) + N + (size_t)sv_area_words(N) * 4);
+    const int f = SOLO ? (int)blockIdx.x : 2 * (int)blockIdx.x + half;
     const bool have_frame = f < n_frames;
     const int lane = tid & 63, wave = tid >> 6;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave); // the same value, known to be uniform (scalar addressing of the records)
     const int NG = N / kM;
     const bool active = tid < kM;
 
@@ -478,7 +906,32 @@ __global__ __launch_bounds__(kThreads, MINW) void ldpc_layered_kernel(
     bool finished = !have_frame; // this half has nothing (more) to do; it still takes part in every barrier
     if (have_frame) {
         tgt = target ? target[f] : cap;
-        if (llr_in) {
+        if (fresh && dm.mode != 0) {
+            // demapper fused into the load: symbol s gives LLRs 2 s, 2 s + 1 (QPSK, natural order) or the three column positions
+            // ra0 + s, ra1 + s, ra2 + s (8PSK de-interleaver), each stored at its place of the internal layout
+            auto put = [&](int n, int8_t v) {
+                int idx = n;
+                if (n >= K) { const int r = n - K, jq = r / q; idx = K + kM * (r - jq * q) + jq; } // pty[360*i + j] = parity[q*j + i]
+                lds[idx] = (uint8_t)v ^ 0x80u;
+            };
+            const float N0 = dm.n0[dm.n0_count > 1 ? f : 0];
+            const float2* src = reinterpret_cast<const float2*>(dm.syms) + (size_t)f * dm.n_syms;
+            if (dm.mode == 1) {
+                const float scalar = qpsk_scalar(N0);
+                for (int sidx = tid; sidx < dm.n_syms; sidx += kHalf) {
+                    const float2 v = src[sidx];
+                    put(2 * sidx, qpsk_llr(v.x, scalar)); put(2 * sidx + 1, qpsk_llr(v.y, scalar));
+                }
+            } else {
+                const float dp = psk8_dist_prec(N0);
+                for (int sidx = tid; sidx < dm.n_syms; sidx += kHalf) {
+                    const float2 v = src[sidx];
+                    int8_t b0, b1, b2;
+                    psk8_llr(v.x, v.y, dm.rr, dm.ri, dp, b0, b1, b2);
+                    put(dm.ra0 + sidx, b0); put(dm.ra1 + sidx, b1); put(dm.ra2 + sidx, b2);
+                }
+            }
+        } else if (fresh) {
             const uint2* src = reinterpret_cast<const uint2*>(llr_in + (size_t)f * N);
             for (int c = tid; c < N / 8; c += kHalf) {
                 uint2 v = src[c];
@@ -506,7 +959,14 @@ __global__ __launch_bounds__(kThreads, MINW) void ldpc_layered_kernel(
         }
     }
     const bool untouched = finished; // never loaded: must not write state/iters/good back
-    if (tid == 0) { flags[0] = 0; flags[2] = 0; flags[3] = 0; flags[1] = finished ? 1 : 0; }
+    if (tid == 0) { flags[0] = 0; flags[2] = 0; flags[3] = 0; flags[1] = finished ? 1 : 0; flags[4] = 0; }
+    // Frame barriers in software (bit 1 of the flag word; pair workgroups only): worth it for high-degree tables without hazard
+    // layers -- few barriers, long layers: S2X B21 +12 %, S2X B10 +10 % -- and a loss where barriers are frequent (B4 -8 %: the
+    // counter costs ~300 cycles per barrier against ~30 for s_barrier). Chosen per table by the host.
+    const bool soft_bar = !SOLO && (stop_on_good & 2);
+    volatile int* hb_ctr = soft_bar ? flags + 4 : nullptr; // frame barrier counter (frame_barrier)
+    int hb_epoch = 0;
+    const int hb_lane = lane;
     __syncthreads();
     TSTAMP(tB); tm_load = tB - tA;
 
@@ -518,6 +978,36 @@ __global__ __launch_bounds__(kThreads, MINW) void ldpc_layered_kernel(
     constexpr int kLayerBytes = MW * kMsgStride * 4;
 #define MSG_LD(soff, w, r4) __builtin_amdgcn_raw_buffer_load_b32(mrs, (r4), (soff) + (w) * (kMsgStride * 4), 0)
 #define MSG_ST(v, soff, w, r4) __builtin_amdgcn_raw_buffer_store_b32((v), mrs, (r4), (soff) + (w) * (kMsgStride * 4), 0)
+    // six-bit message fields (msg_pair16): word w of a check of degree dg holds p6_fields(dg, w) fields; one or two fields are a
+    // 16-bit access (row * 2 inside the word's 1536-byte slot), none is no access at all
+#ifndef DVBS2_P6_DW
+#define DVBS2_P6_DW 3 // fields from which a word is a dword access (experiments: 1 = never use 16-bit accesses)
+#endif
+    // measured (table B4, 4096 frames): 107 k frames/s with byte messages, 93 k with six-bit fields at the same traffic (dword accesses
+    // only), 85-91 k with the traffic actually reduced by a quarter: the unpacking costs more than the bytes bring -- the regular layers
+    // are limited by VALU issue and memory traffic at the same time. Kept behind this switch, off.
+    constexpr bool P6 = false;
+    auto msg_load = [&](uint32_t* dst, int soff, int r4, bool packed, int dg) {
+#pragma unroll
+        for (int w = 0; w < MW; w++) {
+            if (P6 && packed) {
+                const int nf = dg - 5 * w; // uniform
+                if (nf >= DVBS2_P6_DW) dst[w] = MSG_LD(soff, w, r4);
+                else if (nf >= 1) dst[w] = (uint32_t)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(mrs, r4 >> 1, soff + w * (kMsgStride * 4), 1 /* sc0: a sub-dword store does not update a line held in the vector L1 */);
+                else dst[w] = 0u;
+            } else dst[w] = MSG_LD(soff, w, r4);
+        }
+    };
+    auto msg_store = [&](const uint32_t* src, int soff, int r4, bool packed, int dg) {
+#pragma unroll
+        for (int w = 0; w < MW; w++) {
+            if (P6 && packed) {
+                const int nf = dg - 5 * w;
+                if (nf >= DVBS2_P6_DW) MSG_ST(src[w], soff, w, r4);
+                else if (nf >= 1) __builtin_amdgcn_raw_buffer_store_b16((unsigned short)src[w], mrs, r4 >> 1, soff + w * (kMsgStride * 4), 0);
+            } else MSG_ST(src[w], soff, w, r4);
+        }
+    };
     // bnl = 0 before the first update (layered_decoder.hh:27-31,149): a frame's first sweep (it == 0, in the first pass or
     // when a frame that stopped at once is resumed) takes offset-binary zero bytes instead of loading them -- no memset
     // of the record area, no read traffic in sweep 0
@@ -527,7 +1017,7 @@ __global__ __launch_bounds__(kThreads, MINW) void ldpc_layered_kernel(
         TSTAMP(tS0);
         // ---- syndrome test (layered_decoder.hh:32-49, algorithms.hh:195-202): bad if any check has a zero
         // LLR or an odd number of negative LLRs. Barriers are taken by every thread; work only by halves that need it.
-        const bool need_synd = !finished && (stop_on_good || it >= tgt);
+        const bool need_synd = !finished && ((stop_on_good & 1) || it >= tgt);
         // Pre-test (the reference's bad() also returns at the first failing check): the 360 checks of ONE layer,
         // tested edge by edge. A failure here is final; only a frame that passes pays for the full test below.
         if (need_synd && active) {
@@ -546,11 +1036,11 @@ __global__ __launch_bounds__(kThreads, MINW) void ldpc_layered_kernel(
             const int bad_pre = (int)((((x >> 7) ^ (uint32_t)deg) & 1u) | z);
             if (__ballot(bad_pre) != 0 && lane == 0) flags[2] = 1;
         }
-        __syncthreads();
+        lds_barrier();
         const bool need_full = need_synd && flags[2] == 0;
         if (tid == 0) flags[3] = need_full ? 1 : 0;
-        __syncthreads();
-        const bool full_any = flags[3] != 0 || other_flags[3] != 0; // uniform over the workgroup
+        lds_barrier();
+        const bool full_any = flags[3] != 0 || (!soft_bar && !SOLO && other_flags[3] != 0); // uniform over the barrier domain
         if (full_any) {
         if (need_full) {
             // Step 1: 360-bit sign vector per group via wave ballots (4 groups per trip to batch the LDS reads).
@@ -569,14 +1059,14 @@ __global__ __launch_bounds__(kThreads, MINW) void ldpc_layered_kernel(
             if (zero_any != 0 && lane == 0) flags[0] = 1;
         }
         TSTAMP(tC); tm_s1 += tC - tS0;
-        __syncthreads();
+        lds_barrier();
         if (need_full && tid < NG) { // wrap extension: bits 360+u = bit u
             uint32_t* p = sv + tid * kSvWords;
             const uint32_t w0 = p[0], w1 = p[1];
             p[11] = (p[11] & 0xffu) | (w0 << 8);
             p[12] = (w0 >> 24) | (w1 << 8);
         }
-        __syncthreads();
+        lds_barrier();
         if (need_full) {
             // Step 2: parity word (layer i, lanes 32w..32w+31) = xor over entries of the rotated sign vectors
             int bad = 0;
@@ -605,20 +1095,20 @@ __global__ __launch_bounds__(kThreads, MINW) void ldpc_layered_kernel(
             }
             if (__ballot(bad) != 0 && lane == 0) flags[0] = 1;
         }
-        __syncthreads();
+        lds_barrier();
         } // full_any
         if (need_synd) is_good = need_full && flags[0] == 0;
-        if (!finished && (it >= tgt || (stop_on_good && is_good))) finished = true;
-        __syncthreads(); // everyone has read flags[0]
+        if (!finished && (it >= tgt || ((stop_on_good & 1) && is_good))) finished = true;
+        lds_barrier(); // everyone has read flags[0]
         if (tid == 0) { flags[0] = 0; flags[2] = 0; flags[1] = finished ? 1 : 0; }
-        __syncthreads();
+        lds_barrier();
         TSTAMP(tS1); tm_synd += tS1 - tS0;
-        if (finished && other_flags[1]) break; // uniform over the workgroup
+        if (finished && (soft_bar || SOLO || other_flags[1])) break; // uniform over the barrier domain
 
         // ---- one update sweep: layered_decoder.hh:50-79 ----
         // Threads 360..383 of a half mirror check row 359: same reads, same results, same (duplicate) writes. That
         // keeps the whole sweep free of per-lane predicates: `work` is wave-uniform.
-        const bool work = !finished;
+        const bool work = __builtin_amdgcn_readfirstlane(finished ? 0 : 1) != 0; // uniform over the wave, and the compiler knows it
         const int row = tid < kM ? tid : kM - 1;
         const int row4 = row * 4;
         const bool zero_msgs = it == 0; // uniform over the half
@@ -632,21 +1122,34 @@ __global__ __launch_bounds__(kThreads, MINW) void ldpc_layered_kernel(
         // buffered whole; for the large ones only every 8th dword is carried over -- enough to pull each cache
         // line of the next record into the scalar cache -- and the rest is loaded at the top of the layer.
         constexpr int PF = DMAX <= 12 ? 1 : 8;
-        uint32_t nhdr = recs[0];
+        // the sweep reads the records of its own WAVE (check_node_v2): wrecs[(layer * 6 + wave) * RS]
+        const uint32_t* wr = V2 ? wrecs + (size_t)wave_u * rec_stride_wave(DMAX) : recs; // builds without packed nodes read the per-layer records
+        uint32_t nhdr = wr[0], ninfo = wr[1]; // word 1: message format of the NEXT layer for this wave (degree | packed << 8)
         uint32_t nent[2 * DMAX];
 #pragma unroll
-        for (int k = 0; k < 2 * DMAX; k += PF) nent[k] = recs[4 + k];
+        for (int k = 0; k < 2 * DMAX; k += PF) nent[k] = wr[4 + k];
         for (int i = 0; i < q; i++) {
-            const uint32_t hdr = nhdr;
+            const uint32_t hdr = nhdr, info = ninfo;
+            const bool npacked = (info >> 8) & 1u; const int ndeg = (int)(info & 0xffu);
             uint32_t ent[2 * DMAX];
 #pragma unroll
-            for (int k = 0; k < 2 * DMAX; k++) ent[k] = (k % PF == 0) ? nent[k] : recs[(size_t)i * RS + 4 + k];
-            {
-                const uint32_t* nrec = recs + (size_t)(i + 1 < q ? i + 1 : 0) * RS;
-                nhdr = nrec[0];
+            for (int k = 0; k < 2 * DMAX; k++) ent[k] = (k % PF == 0) ? nent[k] : wr[(size_t)i * RSW + 4 + k];
+            const uint32_t* nrec = wr + (size_t)(i + 1 < q ? i + 1 : 0) * RSW;
+            auto prefetch = [&](uint32_t after) {
+#if DVBS2_OPT_NODEPF
+                unsigned long long pv = (unsigned long long)nrec;
+                asm volatile("" : "+s"(pv) : "v"(after)); // ordering only: the loads follow whatever produced `after`
+                const __attribute__((address_space(4))) uint32_t* p = (const __attribute__((address_space(4))) uint32_t*)pv; // constant address space: scalar loads
+#else
+                const uint32_t* p = nrec; (void)after;
+#endif
+                nhdr = p[0]; ninfo = p[1];
 #pragma unroll
-                for (int k = 0; k < 2 * DMAX; k += PF) nent[k] = nrec[4 + k];
-            }
+                for (int k = 0; k < 2 * DMAX; k += PF) nent[k] = p[4 + k];
+            };
+            // a packed-node layer (bit 13) may issue these loads from inside the node; the others here
+            const bool pf_in_node = DVBS2_OPT_NODEPF && ((hdr >> 13) & 1u) && work;
+            if (!pf_in_node) prefetch(0u);
             const int deg = (int)(hdr & 0xffu) + 2;
             const int nc = (int)((hdr >> 8) & 0xfu);
             uint32_t* htab = ((hdr >> 12) & 1u) ? sv : nullptr; // lane-chain scratch: the sign-vector area is idle during a sweep
@@ -654,40 +1157,40 @@ __global__ __launch_bounds__(kThreads, MINW) void ldpc_layered_kernel(
             const bool layer0 = (i == 0);
             const int mso = i * kLayerBytes; // scalar byte offset of this layer's message records
             TSTAMP(tA);
-            if (hdr & 0x8000u) __syncthreads();
+            if (hdr & 0x8000u) lds_barrier();
             TSTAMP(tB); tm_bar += tB - tA;
             if (block >= kM) {
                 // regular layer: all 360 checks at once
                 if (work) {
                     const int jj = row;
+                    const bool v2 = V2 && ((hdr >> 13) & 1u);
+                    // v2: this wave's record is in the packed node's format (two's complement messages)
                     uint32_t mw[MW], nm[MW];
 #pragma unroll
-                    for (int w = 0; w < MW; w++) mw[w] = pre[w];
-                    if (i + 1 < q && !zero_msgs) {
-#pragma unroll
-                        for (int w = 0; w < MW; w++) pre[w] = MSG_LD(mso + kLayerBytes, w, row4);
-                    }
-                    DVBS2_DEG_SWITCH
-#pragma unroll
-                    for (int w = 0; w < MW; w++) MSG_ST(nm[w], mso, w, row4);
+                    for (int w = 0; w < MW; w++) mw[w] = zero_msgs ? (v2 ? 0u : 0x80808080u) : pre[w];
+                    if (i + 1 < q && !zero_msgs) msg_load(pre, mso + kLayerBytes, row4, npacked, ndeg);
+                    if constexpr (V2) { if (v2) { DVBS2_V2_SWITCH } else DVBS2_DEG_SWITCH } else DVBS2_DEG_SWITCH
+                    msg_store(nm, mso, row4, v2, deg);
                 }
                 TSTAMP(tC); tm_body += tC - tB;
+                if (TIMING && tdbg && f == 0 && tid == 0) tdbg[(size_t)n_frames * 48 + i] += tC - tA; // per-layer cycles of frame 0, wave 0 (incl. its barrier)
             } else {
                 if (nc != kHazardWalk) {
                     // sequential-order hazard inside the layer: check_node_hazard (every thread takes every barrier)
                     const int jj = row;
+                    const bool hv2 = V2 && ((hdr >> 13) & 1u);
+                    // hv2: packed single-pair chain (check_node_chain_v2): two's complement messages
                     uint32_t mw[MW], nm[MW];
 #pragma unroll
-                    for (int w = 0; w < MW; w++) mw[w] = work ? pre[w] : 0x80808080u;
-                    if (work && i + 1 < q && !zero_msgs) {
-#pragma unroll
-                        for (int w = 0; w < MW; w++) pre[w] = MSG_LD(mso + kLayerBytes, w, row4);
-                    }
-                    DVBS2_HAZ_SWITCH
-                    if (work) {
-#pragma unroll
-                        for (int w = 0; w < MW; w++) MSG_ST(nm[w], mso, w, row4);
-                    }
+                    for (int w = 0; w < MW; w++) mw[w] = (work && !zero_msgs) ? pre[w] : (hv2 ? 0u : 0x80808080u);
+                    if (work && i + 1 < q && !zero_msgs) msg_load(pre, mso + kLayerBytes, row4, npacked, ndeg);
+                    if constexpr (V2 && DMAX <= 16) { // (the chain node's register state costs the high-degree builds more than it saves: not built there)
+                        if (hv2) {
+                            uint32_t* htab16 = reinterpret_cast<uint32_t*>((reinterpret_cast<size_t>(sv) + 15) & ~(size_t)15); // 16-byte records
+                            DVBS2_CHAIN_SWITCH
+                        } else DVBS2_HAZ_SWITCH
+                    } else DVBS2_HAZ_SWITCH
+                    if (work) msg_store(nm, mso, row4, hv2, deg);
                 } else {
                     // too many hazard entries: the first wave of the half walks the 360 checks alone in ascending
                     // chunks of min(B_i, 64) (LDS operations of one wave execute in order: no barrier between chunks)
@@ -705,17 +1208,15 @@ __global__ __launch_bounds__(kThreads, MINW) void ldpc_layered_kernel(
                             }
                         }
                     }
-                    __syncthreads();
-                    if (work && i + 1 < q && !zero_msgs) {
-#pragma unroll
-                        for (int w = 0; w < MW; w++) pre[w] = MSG_LD(mso + kLayerBytes, w, row4);
-                    }
+                    lds_barrier();
+                    if (work && i + 1 < q && !zero_msgs) msg_load(pre, mso + kLayerBytes, row4, npacked, ndeg);
                 }
                 TSTAMP(tC); tm_conf += tC - tB;
+                if (TIMING && tdbg && f == 0 && tid == 0) tdbg[(size_t)n_frames * 48 + i] += tC - tA;
             }
         }
         TSTAMP(tA);
-        __syncthreads();
+        lds_barrier();
         TSTAMP(tB); tm_bar += tB - tA; tm_sweep += tB - tS1;
         if (!finished) it++;
     }
@@ -729,59 +1230,79 @@ __global__ __launch_bounds__(kThreads, MINW) void ldpc_layered_kernel(
         uint2* dst = reinterpret_cast<uint2*>(state + (size_t)f * N);
         for (int c = tid; c < N / 8; c += kHalf) dst[c] = *reinterpret_cast<const uint2*>(lds + 8 * c);
     }
+    if constexpr (SOLO) { // give the CU's pattern slot back
+        if (tid == 0) __hip_atomic_fetch_add(cu_slots + solo_slot, solo_pat ? -0x10000 : -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 
 // ---- host-side launch interface of one kernel variant (defined in ldpc_inst_*.hip) ----
 struct LdpcLaunch {
-    const uint32_t* recs; const int8_t* llr_in; uint8_t* state; uint32_t* msgs; int* iters; int* good; const int* target;
+    const uint32_t* recs; const uint32_t* wrecs; const int8_t* llr_in; uint8_t* state; uint32_t* msgs; int* iters; int* good; const int* target;
     int n_frames, N, K, q, cap, stop_on_good; unsigned long long* tdbg;
+    DemapFused dm;
     size_t lds_bytes; hipStream_t stream;
     bool dense; // the 80-VGPR build of the kernel (two workgroups per CU), see kDenseBuilt
+    bool v2;    // the build with the packed nodes
+    bool solo;  // one frame per workgroup (kSoloBuilt)
+    int* cu_slots;
 };
-template <int DMAX> hipError_t ldpc_variant_prepare(size_t lds_bytes);
+template <int DMAX> hipError_t ldpc_variant_prepare(size_t pair_lds_bytes, size_t solo_lds_bytes);
 template <int DMAX> void ldpc_variant_launch(const LdpcLaunch& a);
+template <int DMAX> constexpr bool kSoloBuilt = (DMAX <= 16); // 128 VGPRs: four waves per SIMD must fit while a workgroup starts
 
 #ifdef DVBS2_LDPC_INSTANTIATE
 // The cycle-stamped variant (DVBS2_TIMING=1, tools/exp_tables.py) is only built for DMAX = 8 -- the headline tables --
 // to keep the build time of the large variants down; elsewhere the request is ignored.
+#ifdef DVBS2_TIMING_ALL
+template <int DMAX> constexpr bool kTimingBuilt = true; // experiment builds (tools/build_variant.sh timing -DDVBS2_TIMING_ALL)
+#else
 template <int DMAX> constexpr bool kTimingBuilt = (DMAX == 8);
+#endif
 // only the degree class 5..12 survives 80 VGPRs (120 B of scratch); the classes of short 5/6 and 8/9 (DMAX 20, 28) spill so
 // much that they run 8x slower (measured)
 template <int DMAX> constexpr bool kDenseBuilt = (DMAX == 12);
-template <int DMAX> hipError_t ldpc_variant_prepare(size_t lds_bytes)
+#define DVBS2_KARGS a.recs, a.wrecs, a.llr_in, a.state, a.msgs, a.iters, a.good, a.target, a.n_frames, a.N, a.K, a.q, a.cap, a.stop_on_good
+template <int DMAX> hipError_t ldpc_variant_prepare(size_t pair_lds_bytes, size_t solo_lds_bytes)
 {
-    hipError_t e = hipFuncSetAttribute((const void*)ldpc_layered_kernel<DMAX, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    if (e != hipSuccess) return e;
-    if constexpr (kDenseBuilt<DMAX>) {
-        e = hipFuncSetAttribute((const void*)ldpc_layered_kernel<DMAX, false, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        if (e != hipSuccess) return e;
+    auto set = [](const void* k, size_t b) { return hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b); };
+    hipError_t e = set((const void*)ldpc_layered_kernel<DMAX, false, 1, false, false>, pair_lds_bytes);
+    if (e == hipSuccess) e = set((const void*)ldpc_layered_kernel<DMAX, false, 1, true, false>, pair_lds_bytes);
+    if constexpr (kSoloBuilt<DMAX>) {
+        if (e == hipSuccess) e = set((const void*)ldpc_layered_kernel<DMAX, false, 1, false, true>, solo_lds_bytes);
+        if (e == hipSuccess) e = set((const void*)ldpc_layered_kernel<DMAX, false, 1, true, true>, solo_lds_bytes);
     }
-    if constexpr (kTimingBuilt<DMAX>)
-        return hipFuncSetAttribute((const void*)ldpc_layered_kernel<DMAX, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    return hipSuccess;
+    if constexpr (kDenseBuilt<DMAX>) if (e == hipSuccess) e = set((const void*)ldpc_layered_kernel<DMAX, false, 6, false, false>, pair_lds_bytes);
+    if constexpr (kTimingBuilt<DMAX>) if (e == hipSuccess) e = set((const void*)ldpc_layered_kernel<DMAX, true, 1, true, false>, pair_lds_bytes);
+    return e;
 }
 template <int DMAX> void ldpc_variant_launch(const LdpcLaunch& a)
 {
     const dim3 grid((a.n_frames + 1) / 2), block(kThreads);
     if constexpr (kTimingBuilt<DMAX>) {
         if (a.tdbg) {
-            hipLaunchKernelGGL((ldpc_layered_kernel<DMAX, true>), grid, block, a.lds_bytes, a.stream, a.recs, a.llr_in, a.state, a.msgs,
-                               a.iters, a.good, a.target, a.n_frames, a.N, a.K, a.q, a.cap, a.stop_on_good, a.tdbg);
+            hipLaunchKernelGGL((ldpc_layered_kernel<DMAX, true, 1, true, false>), grid, block, a.lds_bytes, a.stream, DVBS2_KARGS, a.tdbg, nullptr, a.dm);
             return;
         }
     }
     if constexpr (kDenseBuilt<DMAX>) {
         if (a.dense) {
-            hipLaunchKernelGGL((ldpc_layered_kernel<DMAX, false, 6>), grid, block, a.lds_bytes, a.stream, a.recs, a.llr_in, a.state, a.msgs,
-                               a.iters, a.good, a.target, a.n_frames, a.N, a.K, a.q, a.cap, a.stop_on_good, nullptr);
+            hipLaunchKernelGGL((ldpc_layered_kernel<DMAX, false, 6, false, false>), grid, block, a.lds_bytes, a.stream, DVBS2_KARGS, nullptr, nullptr, a.dm);
             return;
         }
     }
-    hipLaunchKernelGGL((ldpc_layered_kernel<DMAX, false>), grid, block, a.lds_bytes, a.stream, a.recs, a.llr_in, a.state, a.msgs,
-                       a.iters, a.good, a.target, a.n_frames, a.N, a.K, a.q, a.cap, a.stop_on_good, nullptr);
+    if constexpr (kSoloBuilt<DMAX>) {
+        if (a.solo) {
+            const dim3 sgrid(a.n_frames), sblock(kSoloThreads);
+            if (a.v2) hipLaunchKernelGGL((ldpc_layered_kernel<DMAX, false, 1, true, true>), sgrid, sblock, a.lds_bytes, a.stream, DVBS2_KARGS, nullptr, a.cu_slots, a.dm);
+            else hipLaunchKernelGGL((ldpc_layered_kernel<DMAX, false, 1, false, true>), sgrid, sblock, a.lds_bytes, a.stream, DVBS2_KARGS, nullptr, a.cu_slots, a.dm);
+            return;
+        }
+    }
+    if (a.v2) hipLaunchKernelGGL((ldpc_layered_kernel<DMAX, false, 1, true, false>), grid, block, a.lds_bytes, a.stream, DVBS2_KARGS, nullptr, nullptr, a.dm);
+    else hipLaunchKernelGGL((ldpc_layered_kernel<DMAX, false, 1, false, false>), grid, block, a.lds_bytes, a.stream, DVBS2_KARGS, nullptr, nullptr, a.dm);
 }
-template hipError_t ldpc_variant_prepare<DVBS2_LDPC_INSTANTIATE>(size_t);
+template hipError_t ldpc_variant_prepare<DVBS2_LDPC_INSTANTIATE>(size_t, size_t);
 template void ldpc_variant_launch<DVBS2_LDPC_INSTANTIATE>(const LdpcLaunch&);
 #endif
 

@@ -217,6 +217,8 @@ def make_input(table, kind, n_frames, seed=0, amp=6.0, sigma=4.0):
         return rng.choice(np.array([-128, -127, 127, 126, 0], np.int8), (n_frames, N))
     if kind == "zero":
         return np.zeros((n_frames, N), np.int8)
+    if kind == "clean":  # valid codewords with strong LLRs: the first syndrome test passes, zero updates
+        return llr_codeword_awgn(table, n_frames, seed, amp=20, sigma=0.0)[0]
     raise ValueError(kind)
 
 

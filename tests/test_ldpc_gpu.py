@@ -2,11 +2,13 @@
 packed bits and per-group return values. Checkers: oracle/liboracle.so (plain-C restatement) and, when the
 prebuilt oracle/_ref travelled with the repo, the genuine reference decoders (AVX2 batch = 32 frames,
 generic batch = 16 frames)."""
+import os
+
 import numpy as np
 import pytest
 
 import fec_testlib as T
-from dvbs2rx_amd import ldpc_table_names, LdpcDecoder, capi
+from dvbs2rx_amd import ldpc_table_names, LdpcDecoder, capi, get_fec_info
 
 pytestmark = pytest.mark.gpu
 
@@ -59,15 +61,25 @@ def test_near_threshold_groups(table, amp, sigma, G):
     assert len(ret) == 64 // G
 
 
-@pytest.mark.parametrize("variant", ["policy", "classic"])
+VARIANTS = {  # every build of the sweep kernel gives the same bits (environment overrides of the per-table policy)
+    "policy": {},
+    "classic": {"DVBS2_PR": "0", "DVBS2_DENSE": "0"},                                              # no parity-in-records / dense build
+    "plain": {"DVBS2_PR": "0", "DVBS2_DENSE": "0", "DVBS2_V2": "0", "DVBS2_SOLO": "0"},          # byte messages, scalar nodes, pair workgroups
+    "packed-pair": {"DVBS2_PR": "0", "DVBS2_DENSE": "0", "DVBS2_V2": "1", "DVBS2_SOLO": "0"},    # packed nodes, six-bit messages, pair workgroups
+    "plain-solo": {"DVBS2_PR": "0", "DVBS2_DENSE": "0", "DVBS2_V2": "0", "DVBS2_SOLO": "1"},     # scalar nodes, one frame per workgroup
+    "packed-solo": {"DVBS2_PR": "0", "DVBS2_DENSE": "0", "DVBS2_V2": "1", "DVBS2_SOLO": "1"},
+    "soft-barrier": {"DVBS2_PR": "0", "DVBS2_DENSE": "0", "DVBS2_V2": "1", "DVBS2_SOLO": "0", "DVBS2_SOFT_BARRIER": "1"},  # per-frame software barriers
+}
+
+
+@pytest.mark.parametrize("variant", list(VARIANTS))
 @pytest.mark.parametrize("table", ldpc_table_names())
 def test_every_table_bit_exact(table, variant, monkeypatch):
     """All 57 DVB-S2 / S2X / T2 tables of the reference: never-converging input (fixed trip count)
     and noisy codewords (groups converge at different counts), bit-exact LLRs, bits and return values -- with the kernel
-    variant the library picks for the table and with the classic kernel forced."""
-    if variant == "classic":
-        monkeypatch.setenv("DVBS2_PR", "0")
-        monkeypatch.setenv("DVBS2_DENSE", "0")
+    build the library picks for the table and with every other build forced."""
+    for k, v in VARIANTS[variant].items():
+        monkeypatch.setenv(k, v)
     N = T.ldpc_info(table)[0]
     assert compare(table, T.llr_noise(32, N, 777), 32, 3).tolist() == [-1]
     llr, _ = T.llr_codeword_awgn(table, 32, 4242, amp=12, sigma=3.0)
@@ -136,16 +148,14 @@ def test_device_pointer_entry():
 
 def test_every_table_of_the_reference():
     """All 57 parity tables (every kernel variant / degree case): 3 updates on never-converging input plus a clean
-    codeword, against the genuine reference (oracle for G=32 when oracle/_ref is absent: slower but identical)."""
+    codeword, against the genuine reference (the restatement for G=32 when oracle/_ref is absent: slower, identical). No table is skipped."""
     import json, os
     rows = json.load(open(os.path.join(T.ROOT, "tests", "golden", "fec_params.json")))["rows"]
     tables = sorted({r["table"] for r in rows})
     assert len(tables) == 57
-    fast = T.ref_ldpc() is not None
+    # without oracle/_ref the restatement stands in for every table (slower, same answers: it is pinned by the digests)
     for table in tables:
         N, K, _, _ = T.ldpc_info(table)
-        if not fast and N > 16200:
-            continue
         x = T.llr_noise(32, N, 4242)
         clean, _ = T.llr_codeword_awgn(table, 1, 7, amp=20, sigma=0.0)
         x[31] = clean[0]
@@ -153,6 +163,26 @@ def test_every_table_of_the_reference():
         want, wret = checker(table, x, 32, 3)
         assert ret.tolist() == wret, table
         assert np.array_equal(out, want), table
+
+
+def test_reference_digests_on_gpu():
+    """tests/golden/ldpc_golden.json (digests of the GENUINE reference, tools/gen_ldpc_golden.py): the SURVEY 8(c) grid -- five
+    BASELINE tables x {clean codewords (no update), near threshold, never converging, saturating, all zero} x batch 32 (AVX2)
+    and 16 (generic) -- plus the short / medium / T2 cases, compared by SHA-256 of decoded LLRs, packed bits and return codes.
+    Needs nothing but the committed fixture."""
+    import json, os
+    cases = json.load(open(os.path.join(T.ROOT, "tests", "golden", "ldpc_golden.json")))
+    assert len(cases) >= 38
+    for case in cases:
+        x = T.make_input(case["table"], case["kind"], case["n_frames"], **case["params"])
+        assert T.sha(x) == case["input_sha256"], "input generator drifted"
+        N = x.shape[1]
+        for G in (32, 16):
+            bits, out, ret = run_gpu(case["table"], x, G, case["trials"])
+            want = case["results"][str(G)]
+            assert ret.tolist() == want["ret"], (case["table"], case["kind"], G)
+            assert T.sha(out) == want["llr_sha256"], (case["table"], case["kind"], G)
+            assert T.sha(bits) == want["bits_sha256"], (case["table"], case["kind"], G)
 
 
 def test_ragged_and_empty_batches():
@@ -197,8 +227,9 @@ def test_parity_in_records_variant(monkeypatch, force):
 
 
 def test_kernel_variant_policy(monkeypatch):
-    """Which sweep kernel a handle launches (dvbs2_ldpc_kernel_name): parity-in-records for short/medium frames with
-    check degree <= 7; the classic variant of the table's degree class otherwise."""
+    """Which sweep kernel a handle launches (dvbs2_ldpc_kernel_name): parity-in-records for short/medium frames with check degree
+    <= 7, the 80-VGPR build for hazard-dominated short tables, otherwise the build of the table's degree class that measured
+    fastest (packed nodes and / or one frame per workgroup)."""
     def name(table, **env):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -209,16 +240,27 @@ def test_kernel_variant_policy(monkeypatch):
         for k in env:
             monkeypatch.delenv(k)
         return n
-    assert name("S2_TABLE_B4") == "ldpc_layered_kernel<8>"       # normal frames: classic kernel (hazard layers as lane chains)
-    assert name("S2_TABLE_C1") == "ldpc_layered_pr_kernel"
+    # the build per table is data: csrc/ldpc_policy.inc (generated from an MI355X sweep of the four builds, tools/gen_policy.py)
+    import re
+    pol = {m.group(1): (int(m.group(2)), int(m.group(3))) for m in
+           re.finditer(r'\{ "(\w+)", (\d), (\d) \}', open(os.path.join(T.ROOT, "gr-dvbs2rx_amd", "csrc", "ldpc_policy.inc")).read())}
+    assert len(pol) == 57
+    def expect(table, dmax):
+        packed, solo = pol[table]
+        solo = solo and dmax <= 16
+        return f"ldpc_layered_kernel<{dmax}" + ((", packed, solo>" if packed else ", solo>") if solo else (", packed>" if packed else ">"))
+    assert name("S2_TABLE_B4") == expect("S2_TABLE_B4", 8)
+    assert name("S2_TABLE_B7") == expect("S2_TABLE_B7", 16)
+    assert name("S2_TABLE_B11") == expect("S2_TABLE_B11", 32)
+    assert name("S2X_TABLE_B9") == expect("S2X_TABLE_B9", 16)
+    assert name("S2_TABLE_C1") == "ldpc_layered_pr_kernel"        # short / medium frames of degree <= 7: parity in records
     assert name("S2X_TABLE_C9") == "ldpc_layered_pr_kernel"       # medium frame
-    assert name("S2_TABLE_B1") == "ldpc_layered_kernel<8>"       # 135 thin layers: the classic kernel is faster
-    assert name("S2_TABLE_B7") == "ldpc_layered_kernel<16>"
-    assert name("S2_TABLE_B11") == "ldpc_layered_kernel<32>"
     assert name("S2_TABLE_C5") == "ldpc_layered_kernel<12, dense>"  # short 3/5: 16 of 18 layers are hazard layers
-    assert name("S2_TABLE_C5", DVBS2_DENSE="0") == "ldpc_layered_kernel<12>"
-    assert name("S2X_TABLE_C5") == "ldpc_layered_kernel<12>"      # same degree class, no hazard layers
-    assert name("S2_TABLE_C1", DVBS2_PR="0") == "ldpc_layered_kernel<8>"
+    assert name("S2_TABLE_C5", DVBS2_DENSE="0", DVBS2_V2="0", DVBS2_SOLO="0") == "ldpc_layered_kernel<12>"
+    assert name("S2_TABLE_C1", DVBS2_PR="0", DVBS2_V2="0", DVBS2_SOLO="0") == "ldpc_layered_kernel<8>"
+    assert name("S2_TABLE_B4", DVBS2_V2="1", DVBS2_SOLO="1") == "ldpc_layered_kernel<8, packed, solo>"
+    assert name("S2_TABLE_B4", DVBS2_V2="0", DVBS2_SOLO="0") == "ldpc_layered_kernel<8>"
+    assert name("S2_TABLE_B11", DVBS2_V2="1", DVBS2_SOLO="1") == "ldpc_layered_kernel<32, packed>"  # no one-frame build above 128 VGPRs
     assert name("S2_TABLE_B4", DVBS2_PR="1") == "ldpc_layered_pr_kernel"
     assert name("S2_TABLE_B1", DVBS2_PR="1") == "ldpc_layered_pr_kernel"
 
@@ -283,3 +325,24 @@ def test_async_entry_and_chunked_host_path(monkeypatch):
         bits, out, ret = dec.work(llr, want_llr=True)  # host buffers, chunked
         assert ret.tolist() == wret and np.array_equal(out, want) and np.array_equal(bits, T.pack_bits(want, K))
         dec.close()
+
+
+@pytest.mark.parametrize("framesize,rate", [(capi.FECFRAME_SHORT, "C1_5_VLSNR_SF2"), (capi.FECFRAME_MEDIUM, "C1_5_MEDIUM")])
+def test_rows_whose_bch_length_is_not_the_table_k(framesize, rate):
+    """VL-SNR / medium rows of get_fec_info() where bch.n != K of the parity table (lib/fec_params.cc:291-295, :323-327:
+    2680 vs 3240 on DVB_S2_TABLE_C1, 5840 vs 6480 on DVB_S2X_TABLE_C8): created by (standard, framesize, rate) like the
+    block does, OM_MESSAGE emits the first ldpc.k = bch.n bits of each decoded frame (lib/ldpc_decoder_bb_impl.cc:432-442),
+    the decoder itself works on all N LLRs. Against the genuine reference decoder."""
+    fi = get_fec_info(capi.STANDARD_DVBS2, framesize, rate)
+    N, K, _, _ = T.ldpc_info(fi["table"])
+    assert fi["ldpc_k"] != K and fi["ldpc_n"] == N and fi["ldpc_k"] == fi["bch_n"]
+    dec = LdpcDecoder(standard=capi.STANDARD_DVBS2, framesize=framesize, rate=rate, outputmode=capi.OM_MESSAGE,
+                      max_trials=20, group_size=32, max_frames=64)
+    assert (dec.N, dec.K, dec.message_bits, dec.out_bytes) == (N, K, fi["ldpc_k"], fi["ldpc_k"] // 8)
+    llr, _ = T.llr_codeword_awgn(fi["table"], 64, 311, amp=5, sigma=6.0)
+    llr[40] = T.llr_noise(1, N, 9)[0]
+    bits, out, ret = dec.work(llr, want_llr=True)
+    want, wret = checker(fi["table"], llr, 32, 20)
+    assert ret.tolist() == wret and np.array_equal(out, want)
+    assert np.array_equal(bits, T.pack_bits(want, fi["ldpc_k"]))
+    dec.close()

@@ -114,7 +114,7 @@ def test_qpsk_soft_demap_kat():
 LG = json.load(open(os.path.join(GOLD, "ldpc_golden.json")))
 
 
-@pytest.mark.parametrize("case", LG, ids=lambda c: f"{c['table']}-{c['kind']}")
+@pytest.mark.parametrize("case", LG, ids=lambda c: f"{c['table']}-{c['kind']}-{c['trials']}")
 def test_ldpc_oracle_matches_reference_digests(case):
     x = T.make_input(case["table"], case["kind"], case["n_frames"], **case["params"])
     assert T.sha(x) == case["input_sha256"], "input generator drifted"
