@@ -74,6 +74,7 @@ private:
     size_t lds_bytes_ = 0;
     std::string kname_;
     bool v2_ = false;             // the build with the packed nodes (check_node_v2 / check_node_chain_v2)
+    bool chain_plain_ = false;    // plain sweep kernel with the packed register chain for single-pair hazard layers
     bool soft_bar_ = false;       // per-frame software barriers (high-degree tables without hazard layers)
     bool solo_ = false;           // one frame per workgroup, complementary wave roles per CU (ldpc_kernel.hpp)
     int* d_cu_slots_ = nullptr;   // per-CU pattern counters of the solo kernels

@@ -172,9 +172,12 @@ LdpcDecoderHip::LdpcDecoderHip(const LdpcTableDesc* table, int out_bits_message,
     // single-pair hazard layers walked by the packed register chain (check_node_chain_v2): block <= kChainMaxBlock, the pair are
     // the first two entries (schedule compiler), and on every wave the mixed regular entries fit the fix slots after the pair's
     std::vector<char> chain_v2_layer(sched_.q, 0), chain_order(sched_.q, 0);
-    bool chain_v2 = v2 && dmax_ <= 16; // the packed chain node is only built for the low degree classes
+    chain_plain_ = !pr_ && !dense_ && !v2 && dmax_ <= 16; // plain build + packed chain node (ldpc_kernel.hpp, CHAIN)
+    if (const char* e = getenv("DVBS2_CHAIN_PLAIN")) chain_plain_ = chain_plain_ && atoi(e) != 0;
+    bool chain_v2 = (v2 || chain_plain_) && dmax_ <= 16; // the packed chain node is only built for the low degree classes
     if (const char* e = getenv("DVBS2_CHAIN_V2")) chain_v2 = chain_v2 && atoi(e) != 0;
     for (int i = 1; chain_v2 && i < sched_.q; i++) {
+        if (false) break;
         const LdpcLayer& L = sched_.layers[i];
         if (L.block >= 360 || L.block > kChainMaxBlock || L.n_conflict != 2 || L.cnt < 2) continue;
         const LdpcEntry& a = sched_.entries[L.entry_off], & b = sched_.entries[L.entry_off + 1];
@@ -196,9 +199,9 @@ LdpcDecoderHip::LdpcDecoderHip(const LdpcTableDesc* table, int out_bits_message,
         for (int w = 0; w < 6; w++) {
             uint32_t* rec = &wr[((size_t)i * 6 + w) * RSW];
             std::copy(hr.begin() + (size_t)i * RS, hr.begin() + (size_t)(i + 1) * RS, rec);
-            if (!v2 || i == 0) continue;
+            if (i == 0) continue;
             const bool chain2 = L.block < 360 && chain_v2_layer[i];
-            if (L.block < 360 && !chain2) continue;
+            if (L.block < 360 ? !chain2 : !v2) continue;
             const int lo = 64 * w, hi = std::min(64 * w + 63, 359);
             std::vector<int> mixed, plain;
             auto is_mixed = [&](int k) { const int thr = 360 - (int)sched_.entries[L.entry_off + k].rot; return lo < thr && thr <= hi; };
@@ -232,6 +235,10 @@ LdpcDecoderHip::LdpcDecoderHip(const LdpcTableDesc* table, int out_bits_message,
             put(L.cnt + 1, false); // previous parity (rot 0 for i > 0)
         }
     }
+    if (chain_plain_) { // the per-layer records of the plain build point chain layers to their per-wave records (bit 14)
+        for (int i = 0; i < sched_.q; i++) if (chain_v2_layer[i]) hr[(size_t)i * RS] |= 1u << 14;
+        HIP_OK(hipMemcpy(d_recs_, hr.data(), hr.size() * 4, hipMemcpyHostToDevice));
+    }
     // word 1 of a record: message format of the NEXT layer for the same wave (the sweep loads messages one layer ahead)
     for (int i = 0; i + 1 < sched_.q; i++)
         for (int w = 0; w < 6; w++) {
@@ -257,7 +264,7 @@ LdpcDecoderHip::LdpcDecoderHip(const LdpcTableDesc* table, int out_bits_message,
     soft_bar_ = !pr_ && !dense_ && !solo_ && dmax_ >= 20 && sched_.conflict_layers == 0; // frame barriers in software (ldpc_kernel.hpp)
     if (const char* e = getenv("DVBS2_SOFT_BARRIER")) soft_bar_ = !pr_ && !dense_ && !solo_ && atoi(e) != 0;
     if (solo_) { HIP_OK(hipMalloc(&d_cu_slots_, kCuSlots * 4)); HIP_OK(hipMemset(d_cu_slots_, 0, kCuSlots * 4)); }
-    kname_ = pr_ ? std::string("ldpc_layered_pr_kernel") : "ldpc_layered_kernel<" + std::to_string(dmax_) + (dense_ ? ", dense>" : solo_ ? (v2_ ? ", packed, solo>" : ", solo>") : (v2_ ? ", packed>" : ">"));
+    kname_ = pr_ ? std::string("ldpc_layered_pr_kernel") : "ldpc_layered_kernel<" + std::to_string(dmax_) + (dense_ ? ", dense>" : std::string(v2_ ? ", packed" : chain_plain_ ? ", chain" : "") + (solo_ ? ", solo>" : ">"));
     lds_bytes_ = pr_ ? pr_lds_bytes(sched_.N, sched_.K) : 2 * half_lds_bytes(sched_.N);
     if (const char* e = getenv("DVBS2_LDS_PAD")) lds_bytes_ += (size_t)atoi(e); // occupancy experiments only
     if (pr_) HIP_OK(ldpc_pr_prepare(lds_bytes_));
@@ -289,7 +296,7 @@ void LdpcDecoderHip::launch_sweep(const int8_t* in, bool resume, int stop_on_goo
     la.iters = d_iters_ + fb; la.good = d_good_ + fb; la.target = resume ? d_target_ + fb : nullptr;
     la.n_frames = n_frames; la.N = sched_.N; la.K = sched_.K; la.q = sched_.q; la.cap = max_trials; la.stop_on_good = stop_on_good | (soft_bar_ ? 2 : 0);
     la.tdbg = d_tdbg_; la.lds_bytes = solo_ ? half_lds_bytes(sched_.N) : lds_bytes_; la.stream = stream; la.dense = dense_;
-    la.v2 = v2_; la.solo = solo_; la.cu_slots = d_cu_slots_;
+    la.v2 = v2_; la.solo = solo_; la.chain = chain_plain_; la.cu_slots = d_cu_slots_;
     la.dm = DemapFused{};
     if (dm && !resume) la.dm = *dm;
     if (pr_) ldpc_pr_launch(la);

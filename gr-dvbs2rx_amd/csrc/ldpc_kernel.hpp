@@ -36,16 +36,6 @@ __host__ __device__ constexpr size_t half_lds_bytes(int N) { return ((size_t)N +
 
 __device__ __forceinline__ int wrap360(int t) { return t >= kM ? t - kM : t; }
 
-// experiment switches (build with -DDVBS2_OPT_x=0/1)
-#ifndef DVBS2_OPT_LDSBAR
-#define DVBS2_OPT_LDSBAR 0
-#endif
-#ifndef DVBS2_OPT_NODEPF
-#define DVBS2_OPT_NODEPF 0
-#endif
-#ifndef DVBS2_OPT_HALFBAR
-#define DVBS2_OPT_HALFBAR 0
-#endif
 // Barrier of ONE FRAME's six waves. The two frames of a workgroup share a CU only to get three waves on every SIMD
 // (2+1 / 1+2: two separate 6-wave workgroups land 4,2,3,3 -- tools/ubench/placement.hip); nothing else couples them.
 // With the hardware barrier both frames stall whenever either one is waiting for its slowest wave, for an LDS round trip
@@ -335,16 +325,11 @@ __device__ __forceinline__ void check_node_v2(const uint32_t* ent /*record words
         a[j] = __builtin_elementwise_max(d[j], __builtin_elementwise_sub_sat(as_v2s(0u), d[j])); // |inp| << 8 (0x7fff for -128 and for saturated halves)
     }
     __builtin_amdgcn_s_setprio(1);
-    // The scalar loads of the NEXT layer's record are issued HERE: scalar memory shares its counter with LDS and returns
-    // out of order, so while one is in flight every wait for an LDS read degenerates to "wait for everything"; from this
-    // point to the end of the node there are only LDS writes, and the ~100 VALU instructions that follow cover the load
-    // even when it misses the scalar cache (the per-wave records of a table no longer fit it).
-    // (the record pointer is made to depend on the xor of all inputs, so the loads cannot be placed above the last LDS wait)
-#if DVBS2_OPT_NODEPF
-    __builtin_amdgcn_sched_barrier(0);
-    prefetch_next_record(sx);
-    __builtin_amdgcn_sched_barrier(0);
-#endif
+    // (Issuing the NEXT layer's scalar record loads from this point -- scalar memory shares its counter with LDS, so a load in
+    // flight turns every LDS wait into "wait for everything" -- was tried with a scheduling barrier and an ordering dependency:
+    // it cost 9 % on table B4 and a factor 4 on the degree-30 class through what it does to register allocation. The loads stay
+    // at the top of the layer)
+    (void)prefetch_next_record;
     int mg[DEG];
 #pragma unroll
     for (int k = 0; k < DEG; k++) mg[k] = (k & 1) ? (int)(as_u32(a[k >> 1]) >> 16) : (int)(as_u32(a[k >> 1]) & 0xffffu);
@@ -827,7 +812,7 @@ __device__ __forceinline__ uint32_t hw_cu_index()
 }
 constexpr int kCuSlots = 16 * 8 * 2 * 16;
 
-template <int DMAX, bool TIMING, int MINW = 1, bool V2 = false, bool SOLO = false>
+template <int DMAX, bool TIMING, int MINW = 1, bool V2 = false, bool SOLO = false, bool CHAIN = false /*V2 = false only: the packed chain node alone*/>
 __global__ __launch_bounds__(SOLO ? kSoloThreads : kThreads, SOLO ? 4 : MINW) void ldpc_layered_kernel(
     const uint32_t* __restrict__ recs, const uint32_t* __restrict__ wrecs /*per (layer, wave) sweep records*/,
     const int8_t* __restrict__ llr_in, uint8_t* __restrict__ state,
@@ -1136,20 +1121,13 @@ __global__ __launch_bounds__(SOLO ? kSoloThreads : kThreads, SOLO ? 4 : MINW) vo
             for (int k = 0; k < 2 * DMAX; k++) ent[k] = (k % PF == 0) ? nent[k] : wr[(size_t)i * RSW + 4 + k];
             const uint32_t* nrec = wr + (size_t)(i + 1 < q ? i + 1 : 0) * RSW;
             auto prefetch = [&](uint32_t after) {
-#if DVBS2_OPT_NODEPF
-                unsigned long long pv = (unsigned long long)nrec;
-                asm volatile("" : "+s"(pv) : "v"(after)); // ordering only: the loads follow whatever produced `after`
-                const __attribute__((address_space(4))) uint32_t* p = (const __attribute__((address_space(4))) uint32_t*)pv; // constant address space: scalar loads
-#else
                 const uint32_t* p = nrec; (void)after;
-#endif
                 nhdr = p[0]; ninfo = p[1];
 #pragma unroll
                 for (int k = 0; k < 2 * DMAX; k += PF) nent[k] = p[4 + k];
             };
             // a packed-node layer (bit 13) may issue these loads from inside the node; the others here
-            const bool pf_in_node = DVBS2_OPT_NODEPF && ((hdr >> 13) & 1u) && work;
-            if (!pf_in_node) prefetch(0u);
+            prefetch(0u);
             const int deg = (int)(hdr & 0xffu) + 2;
             const int nc = (int)((hdr >> 8) & 0xfu);
             uint32_t* htab = ((hdr >> 12) & 1u) ? sv : nullptr; // lane-chain scratch: the sign-vector area is idle during a sweep
@@ -1178,13 +1156,21 @@ __global__ __launch_bounds__(SOLO ? kSoloThreads : kThreads, SOLO ? 4 : MINW) vo
                 if (nc != kHazardWalk) {
                     // sequential-order hazard inside the layer: check_node_hazard (every thread takes every barrier)
                     const int jj = row;
-                    const bool hv2 = V2 && ((hdr >> 13) & 1u);
-                    // hv2: packed single-pair chain (check_node_chain_v2): two's complement messages
+                    // hv2: packed single-pair chain (check_node_chain_v2): two's complement messages. In a build without the packed regular
+                    // node (CHAIN) the layer's per-wave record is fetched here, from wrecs, when the per-layer record says so (bit 14).
+                    const bool hv2 = (V2 && ((hdr >> 13) & 1u)) || (!V2 && CHAIN && ((hdr >> 14) & 1u));
+                    if constexpr (!V2 && CHAIN) {
+                        if (hv2) {
+                            const uint32_t* cw = wrecs + ((size_t)i * 6 + wave_u) * rec_stride_wave(DMAX) + 4;
+#pragma unroll
+                            for (int k = 0; k < 2 * DMAX; k++) ent[k] = cw[k];
+                        }
+                    }
                     uint32_t mw[MW], nm[MW];
 #pragma unroll
                     for (int w = 0; w < MW; w++) mw[w] = (work && !zero_msgs) ? pre[w] : (hv2 ? 0u : 0x80808080u);
                     if (work && i + 1 < q && !zero_msgs) msg_load(pre, mso + kLayerBytes, row4, npacked, ndeg);
-                    if constexpr (V2 && DMAX <= 16) { // (the chain node's register state costs the high-degree builds more than it saves: not built there)
+                    if constexpr ((V2 || CHAIN) && DMAX <= 16) { // (the chain node's register state costs the high-degree builds more than it saves: not built there)
                         if (hv2) {
                             uint32_t* htab16 = reinterpret_cast<uint32_t*>((reinterpret_cast<size_t>(sv) + 15) & ~(size_t)15); // 16-byte records
                             DVBS2_CHAIN_SWITCH
@@ -1245,11 +1231,15 @@ struct LdpcLaunch {
     bool dense; // the 80-VGPR build of the kernel (two workgroups per CU), see kDenseBuilt
     bool v2;    // the build with the packed nodes
     bool solo;  // one frame per workgroup (kSoloBuilt)
+    bool chain; // plain build + packed chain node (kChainBuilt; ignored with v2, which has it anyway)
     int* cu_slots;
 };
 template <int DMAX> hipError_t ldpc_variant_prepare(size_t pair_lds_bytes, size_t solo_lds_bytes);
 template <int DMAX> void ldpc_variant_launch(const LdpcLaunch& a);
-template <int DMAX> constexpr bool kSoloBuilt = (DMAX <= 16); // 128 VGPRs: four waves per SIMD must fit while a workgroup starts
+template <int DMAX> constexpr bool kSoloBuilt = (DMAX <= 16);
+// plain builds with the packed chain node: measured SLOWER than the plain build's own lane chain (B4 107.8 k vs 109.8 k, B5 57.9 k vs
+// 62.2 k frames/s) although its ordered steps cost a third -- the node's register state hurts the rest of the kernel. Not built.
+template <int DMAX> constexpr bool kChainBuilt = false; // 128 VGPRs: four waves per SIMD must fit while a workgroup starts
 
 #ifdef DVBS2_LDPC_INSTANTIATE
 // The cycle-stamped variant (DVBS2_TIMING=1, tools/exp_tables.py) is only built for DMAX = 8 -- the headline tables --
@@ -1271,6 +1261,10 @@ template <int DMAX> hipError_t ldpc_variant_prepare(size_t pair_lds_bytes, size_
     if constexpr (kSoloBuilt<DMAX>) {
         if (e == hipSuccess) e = set((const void*)ldpc_layered_kernel<DMAX, false, 1, false, true>, solo_lds_bytes);
         if (e == hipSuccess) e = set((const void*)ldpc_layered_kernel<DMAX, false, 1, true, true>, solo_lds_bytes);
+    }
+    if constexpr (kChainBuilt<DMAX>) {
+        if (e == hipSuccess) e = set((const void*)ldpc_layered_kernel<DMAX, false, 1, false, false, true>, pair_lds_bytes);
+        if (e == hipSuccess) e = set((const void*)ldpc_layered_kernel<DMAX, false, 1, false, true, true>, solo_lds_bytes);
     }
     if constexpr (kDenseBuilt<DMAX>) if (e == hipSuccess) e = set((const void*)ldpc_layered_kernel<DMAX, false, 6, false, false>, pair_lds_bytes);
     if constexpr (kTimingBuilt<DMAX>) if (e == hipSuccess) e = set((const void*)ldpc_layered_kernel<DMAX, true, 1, true, false>, pair_lds_bytes);
@@ -1295,11 +1289,16 @@ template <int DMAX> void ldpc_variant_launch(const LdpcLaunch& a)
         if (a.solo) {
             const dim3 sgrid(a.n_frames), sblock(kSoloThreads);
             if (a.v2) hipLaunchKernelGGL((ldpc_layered_kernel<DMAX, false, 1, true, true>), sgrid, sblock, a.lds_bytes, a.stream, DVBS2_KARGS, nullptr, a.cu_slots, a.dm);
+            else if (a.chain) hipLaunchKernelGGL((ldpc_layered_kernel<DMAX, false, 1, false, true, true>), sgrid, sblock, a.lds_bytes, a.stream, DVBS2_KARGS, nullptr, a.cu_slots, a.dm);
             else hipLaunchKernelGGL((ldpc_layered_kernel<DMAX, false, 1, false, true>), sgrid, sblock, a.lds_bytes, a.stream, DVBS2_KARGS, nullptr, a.cu_slots, a.dm);
             return;
         }
     }
     if (a.v2) hipLaunchKernelGGL((ldpc_layered_kernel<DMAX, false, 1, true, false>), grid, block, a.lds_bytes, a.stream, DVBS2_KARGS, nullptr, nullptr, a.dm);
+    else if constexpr (kChainBuilt<DMAX>) {
+        if (a.chain) hipLaunchKernelGGL((ldpc_layered_kernel<DMAX, false, 1, false, false, true>), grid, block, a.lds_bytes, a.stream, DVBS2_KARGS, nullptr, nullptr, a.dm);
+        else hipLaunchKernelGGL((ldpc_layered_kernel<DMAX, false, 1, false, false>), grid, block, a.lds_bytes, a.stream, DVBS2_KARGS, nullptr, nullptr, a.dm);
+    }
     else hipLaunchKernelGGL((ldpc_layered_kernel<DMAX, false, 1, false, false>), grid, block, a.lds_bytes, a.stream, DVBS2_KARGS, nullptr, nullptr, a.dm);
 }
 template hipError_t ldpc_variant_prepare<DVBS2_LDPC_INSTANTIATE>(size_t, size_t);
