@@ -91,14 +91,41 @@ LdpcDecoderHip::LdpcDecoderHip(const LdpcTableDesc* table, int out_bits_message,
     HIP_OK(hipSetDevice(device_));
     const int RS = rec_stride(dmax_);
     std::vector<uint32_t> hr((size_t)sched_.q * RS, 0);
+    // Which build of the sweep kernel: measured per table (ldpc_policy.inc <- tools/policy_sweep.py + tools/gen_policy.py); a table
+    // that is not listed takes the plain pair kernel. DVBS2_V2 / DVBS2_SOLO override (tests run every build on every table).
+    bool pol_packed = false, pol_solo = false;
+    {
+        struct Pol { const char* table; int packed, solo; };
+        static const Pol kPolicy[] = {
+#include "ldpc_policy.inc"
+        };
+        for (const Pol& p : kPolicy) if (!strcmp(p.table, table->name)) { pol_packed = p.packed; pol_solo = p.solo; }
+    }
+    // The build with the heavy-hazard paths (HZ2: up to twelve ordered entries per check instead of the one-wave walk, two-level walk
+    // where one hazard pair is much closer than the rest): tables listed in ldpc_policy_hz2.inc (measured, tools/hz2_sweep.sh).
+    hz2_ = false;
+    {
+        static const char* const kHz2[] = {
+#include "ldpc_policy_hz2.inc"
+        };
+        for (const char* n : kHz2) if (!strcmp(n, table->name)) hz2_ = true;
+    }
+    if (const char* e = getenv("DVBS2_HZ2")) hz2_ = atoi(e) != 0;
+    {   // (not for tables that run the 80-VGPR build, chosen below by the same rule)
+        bool dense = sched_.N < 64800 && dmax_ == 12 && 10 * sched_.conflict_layers >= 7 * sched_.q && 4 * half_lds_bytes(sched_.N) <= 160 * 1024;
+        if (const char* e = getenv("DVBS2_DENSE")) dense = dmax_ == 12 && atoi(e) != 0 && 4 * half_lds_bytes(sched_.N) <= 160 * 1024;
+        hz2_ = hz2_ && dmax_ >= 12 && !dense;
+    }
+    bool two_level_on = true;
+    if (const char* e = getenv("DVBS2_TWO_LEVEL")) two_level_on = atoi(e) != 0; // experiments / tests
     int lane_chain_max = 128; // measured: gains up to block 64, flat to 128, slightly negative at 180 (three steps per layer)
     if (const char* e = getenv("DVBS2_LANE_CHAIN_MAX")) lane_chain_max = std::min(180, atoi(e)); // experiments
     for (int i = 0; i < sched_.q; i++) {
         const LdpcLayer& L = sched_.layers[i];
         uint32_t nc_code = 0;
         if (L.block < 360) {
-            nc_code = L.n_conflict <= 2 ? 2 : L.n_conflict <= 4 ? 4 : 8;
-            if (L.n_conflict > kMaxHazard || (int)nc_code > L.cnt) nc_code = kHazardWalk;
+            nc_code = L.n_conflict <= 2 ? 2 : L.n_conflict <= 4 ? 4 : L.n_conflict <= 8 ? 8 : 12;
+            if (L.n_conflict > (hz2_ ? kMaxHazardHz2 : kMaxHazard) || (int)nc_code > L.cnt) nc_code = kHazardWalk;
         }
         // A layer whose only hazard is ONE pair (two entries of one group) with a small block is walked as a lane
         // chain (check_node_hazard): the pair is ordered so that entry 0's bit of row j is entry 1's bit of row
@@ -116,7 +143,28 @@ LdpcDecoderHip::LdpcDecoderHip(const LdpcTableDesc* table, int out_bits_message,
                 else if (360 - D == L.block) { order[0] = 1; order[1] = 0; chain = 1; }
             }
         }
+        // Two-level walk (check_node_hazard): ONE pair of hazard entries is closer than every other pair by a factor of two or more.
+        // It goes first (entries 0, 1); word 2 of the record = the distance of the nearest OTHER pair = rows per outer block.
+        uint32_t block2 = 0;
+        if (hz2_ && two_level_on && L.block < 360 && nc_code >= 4 && nc_code != (uint32_t)kHazardWalk) {
+            int best_a = -1, best_b = -1, d1 = 360, d2 = 360;
+            for (int a = 0; a < L.n_conflict; a++)
+                for (int b = a + 1; b < L.n_conflict; b++) {
+                    const LdpcEntry& ea = sched_.entries[L.entry_off + a], & eb = sched_.entries[L.entry_off + b];
+                    if (ea.base != eb.base) continue;
+                    const int d = std::abs((int)ea.rot - (int)eb.rot), dist = std::min(d, 360 - d);
+                    if (dist < d1) { d2 = d1; d1 = dist; best_a = a; best_b = b; }
+                    else d2 = std::min(d2, dist);
+                }
+            if (best_a >= 0 && d1 == L.block && d2 >= 2 * d1 && 360 / d1 - 360 / d2 >= 3) {
+                block2 = (uint32_t)d2;
+                order[0] = best_a; order[1] = best_b;
+                int n = 2;
+                for (int k = 0; k < L.n_conflict; k++) if (k != best_a && k != best_b) order[n++] = k;
+            }
+        }
         hr[(size_t)i * RS] = L.cnt | (nc_code << 8) | (chain << 12) | ((uint32_t)L.sync_before << 15) | ((uint32_t)L.block << 16);
+        hr[(size_t)i * RS + 2] = block2;
         for (int k = 0; k < L.cnt + 2; k++) {
             const LdpcEntry& e = sched_.entries[L.entry_off + order[k]];
             hr[(size_t)i * RS + 4 + 2 * k] = (uint32_t)e.base + e.rot;
@@ -154,26 +202,16 @@ LdpcDecoderHip::LdpcDecoderHip(const LdpcTableDesc* table, int out_bits_message,
     // for each of the six waves of a frame, its data entries reordered "mixed first" (mixed = the wrap point 360 - rot lies
     // inside the wave's rows), window offsets pre-adjusted for the wave, and the lane masks of the mixed entries; a wave
     // with more mixed entries than fix slots, layer 0 and hazard layers keep the classic record (replicated).
-    // Which build of the sweep kernel: measured per table (ldpc_policy.inc <- tools/policy_sweep.py + tools/gen_policy.py); a table
-    // that is not listed takes the plain pair kernel. DVBS2_V2 / DVBS2_SOLO override (tests run every build on every table).
-    bool pol_packed = false, pol_solo = false;
-    {
-        struct Pol { const char* table; int packed, solo; };
-        static const Pol kPolicy[] = {
-#include "ldpc_policy.inc"
-        };
-        for (const Pol& p : kPolicy) if (!strcmp(p.table, table->name)) { pol_packed = p.packed; pol_solo = p.solo; }
-    }
-    bool v2 = !pr_ && !dense_ && pol_packed; // (the 80-VGPR build has no packed nodes)
-    if (const char* e = getenv("DVBS2_V2")) v2 = !pr_ && !dense_ && atoi(e) != 0;
+    bool v2 = !pr_ && !dense_ && !hz2_ && pol_packed; // (the 80-VGPR build has no packed nodes)
+    if (const char* e = getenv("DVBS2_V2")) v2 = !pr_ && !dense_ && !hz2_ && atoi(e) != 0;
     v2_ = v2;
     const int RSW = rec_stride_wave(dmax_);
     std::vector<uint32_t> wr((size_t)sched_.q * 6 * RSW, 0);
     // single-pair hazard layers walked by the packed register chain (check_node_chain_v2): block <= kChainMaxBlock, the pair are
     // the first two entries (schedule compiler), and on every wave the mixed regular entries fit the fix slots after the pair's
     std::vector<char> chain_v2_layer(sched_.q, 0), chain_order(sched_.q, 0);
-    chain_plain_ = !pr_ && !dense_ && !v2 && dmax_ <= 16; // plain build + packed chain node (ldpc_kernel.hpp, CHAIN)
-    if (const char* e = getenv("DVBS2_CHAIN_PLAIN")) chain_plain_ = chain_plain_ && atoi(e) != 0;
+    chain_plain_ = false; // plain build + packed chain node (ldpc_kernel.hpp, CHAIN): measured slower, not built (kChainBuilt); experiments only
+    if (const char* e = getenv("DVBS2_CHAIN_PLAIN")) chain_plain_ = !pr_ && !dense_ && !v2 && dmax_ <= 16 && atoi(e) != 0;
     bool chain_v2 = (v2 || chain_plain_) && dmax_ <= 16; // the packed chain node is only built for the low degree classes
     if (const char* e = getenv("DVBS2_CHAIN_V2")) chain_v2 = chain_v2 && atoi(e) != 0;
     for (int i = 1; chain_v2 && i < sched_.q; i++) {
@@ -258,13 +296,13 @@ LdpcDecoderHip::LdpcDecoderHip(const LdpcTableDesc* table, int out_bits_message,
     HIP_OK(hipEventCreate(&ev0_));
     HIP_OK(hipEventCreate(&ev1_));
     if (getenv("DVBS2_TIMING")) { HIP_OK(hipMalloc(&d_tdbg_, ((size_t)max_frames_ * 48 + 512) * 8)); HIP_OK(hipMemset(d_tdbg_, 0, ((size_t)max_frames_ * 48 + 512) * 8)); }
-    solo_ = !pr_ && !dense_ && dmax_ <= 16 && pol_solo;
-    if (const char* e = getenv("DVBS2_SOLO")) solo_ = !pr_ && !dense_ && dmax_ <= 16 && atoi(e) != 0;
+    solo_ = !pr_ && !dense_ && !hz2_ && dmax_ <= 16 && pol_solo;
+    if (const char* e = getenv("DVBS2_SOLO")) solo_ = !pr_ && !dense_ && !hz2_ && dmax_ <= 16 && atoi(e) != 0;
     if (d_tdbg_) solo_ = false;
     soft_bar_ = !pr_ && !dense_ && !solo_ && dmax_ >= 20 && sched_.conflict_layers == 0; // frame barriers in software (ldpc_kernel.hpp)
     if (const char* e = getenv("DVBS2_SOFT_BARRIER")) soft_bar_ = !pr_ && !dense_ && !solo_ && atoi(e) != 0;
     if (solo_) { HIP_OK(hipMalloc(&d_cu_slots_, kCuSlots * 4)); HIP_OK(hipMemset(d_cu_slots_, 0, kCuSlots * 4)); }
-    kname_ = pr_ ? std::string("ldpc_layered_pr_kernel") : "ldpc_layered_kernel<" + std::to_string(dmax_) + (dense_ ? ", dense>" : std::string(v2_ ? ", packed" : chain_plain_ ? ", chain" : "") + (solo_ ? ", solo>" : ">"));
+    kname_ = pr_ ? std::string("ldpc_layered_pr_kernel") : "ldpc_layered_kernel<" + std::to_string(dmax_) + (dense_ ? ", dense>" : std::string(v2_ ? ", packed" : chain_plain_ ? ", chain" : "") + (solo_ ? ", solo>" : hz2_ ? ", hz2>" : ">"));
     lds_bytes_ = pr_ ? pr_lds_bytes(sched_.N, sched_.K) : 2 * half_lds_bytes(sched_.N);
     if (const char* e = getenv("DVBS2_LDS_PAD")) lds_bytes_ += (size_t)atoi(e); // occupancy experiments only
     if (pr_) HIP_OK(ldpc_pr_prepare(lds_bytes_));
@@ -296,7 +334,7 @@ void LdpcDecoderHip::launch_sweep(const int8_t* in, bool resume, int stop_on_goo
     la.iters = d_iters_ + fb; la.good = d_good_ + fb; la.target = resume ? d_target_ + fb : nullptr;
     la.n_frames = n_frames; la.N = sched_.N; la.K = sched_.K; la.q = sched_.q; la.cap = max_trials; la.stop_on_good = stop_on_good | (soft_bar_ ? 2 : 0);
     la.tdbg = d_tdbg_; la.lds_bytes = solo_ ? half_lds_bytes(sched_.N) : lds_bytes_; la.stream = stream; la.dense = dense_;
-    la.v2 = v2_; la.solo = solo_; la.chain = chain_plain_; la.cu_slots = d_cu_slots_;
+    la.v2 = v2_; la.solo = solo_; la.chain = chain_plain_; la.hz2 = hz2_; la.cu_slots = d_cu_slots_;
     la.dm = DemapFused{};
     if (dm && !resume) la.dm = *dm;
     if (pr_) ldpc_pr_launch(la);

@@ -544,11 +544,12 @@ __device__ __forceinline__ void check_node_chain_v2(const uint32_t* ent /*S0w[DM
 __host__ __device__ constexpr int lane_chain_words(int block) { return (kM + block) + (kM + block + 3) / 4; }
 constexpr int kLaneChainMaxDeg = 28;                                  // not instantiated for the big variants nor for the
                                                                       // 80-VGPR parity-in-records kernel (registers)
-constexpr int kMaxHazard = 8;
+constexpr int kMaxHazard = 8;     // ordered entries per check in the common builds, kMaxHazardHz2 in the HZ2 builds (ldpc_layered_kernel)
+constexpr int kMaxHazardHz2 = 12;
 constexpr int kHazardWalk = 15; // header code: too many hazard entries, fall back to the single-wave chunk walk
-template <int DEG, int NC, bool LAYER0, bool PR = false, bool LAST = false>
+template <int DEG, int NC, bool LAYER0, bool PR = false, bool LAST = false, bool TWO = false /*two-level walk compiled in*/>
 __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, const uint32_t* ent, int jj, int lb, bool work,
-                                                  int block, const uint32_t* mw, uint32_t* nm, int own_in, int* carry,
+                                                  int block, int block2 /*two-level walk: rows per outer block, 0 = off*/, const uint32_t* mw, uint32_t* nm, int own_in, int* carry,
                                                   uint32_t* tab /*lane_chain_words(block) of LDS scratch when the layer is a lane chain*/,
                                                   volatile int* hb_ctr, int& hb_epoch, const int hb_lane /*frame barrier state*/)
 {
@@ -671,8 +672,71 @@ __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, con
             if (jj + block >= kM) lds_wr(ad[0], sat_sum_u8(inp[0], hout[0]));
         }
     }
-    int rel = (work && !lane_chain) ? jj : 0x40000000;
-    for (int start = lane_chain ? kM : 0; start < kM; start += block, rel -= block) {
+    // TWO-LEVEL WALK (NC >= 4, block2 > 0). The block size B is the distance of the NEAREST hazard pair only; every other pair
+    // of hazard entries is at least block2 >= 2 B rows apart. So the rows are walked in outer blocks of block2 rows: at its start the
+    // rows of an outer block read their FAR hazard entries (2 .. NC-1: final with respect to all earlier outer blocks, untouched
+    // inside this one) and fold them into the partial result; then only the near pair (entries 0, 1; host-ordered) goes through the
+    // ordered steps of B rows -- a two-entry step instead of an NC-entry one -- and at the end of the outer block its rows write the
+    // far entries back. 360 / B short steps + 360 / block2 long ones instead of 360 / B long ones (B11 layer 5: B = 4).
+    bool two_level = false;
+    if constexpr (NC >= 4 && TWO) two_level = block2 > 0;
+    if constexpr (NC >= 4 && TWO) if (two_level) {
+        for (int sb = 0; sb < kM; sb += block2) {
+            const bool in_sb = work && (uint32_t)(jj - sb) < (uint32_t)block2;
+            int minF = min0, signsF = signs;
+            if (in_sb) {
+                int Lh[NC];
+#pragma unroll
+                for (int k = 2; k < NC; k++) Lh[k] = lds_rd(ad[k]);
+#pragma unroll
+                for (int k = 2; k < NC; k++) {
+                    inp[k] = min(max(Lh[k] - hmb[k], -128), 127);
+                    mg[k] = mag_offset(Lh[k], hmb[k]);
+                    signsF ^= inp[k];
+                    minF = min(minF, mg[k]);
+                }
+            }
+            const int sb_end = min(sb + block2, kM);
+            int rel = in_sb ? jj - sb : 0x40000000;
+            for (int start = sb; start < sb_end; start += block, rel -= block) {
+                if ((uint32_t)rel < (uint32_t)block) {
+                    const int L0 = lds_rd(ad[0]), L1 = lds_rd(ad[1]);
+                    inp[0] = min(max(L0 - hmb[0], -128), 127);
+                    inp[1] = min(max(L1 - hmb[1], -128), 127);
+                    mg[0] = mag_offset(L0, hmb[0]);
+                    mg[1] = mag_offset(L1, hmb[1]);
+                    const int o0 = min(mg[1], minF), o1 = min(mg[0], minF);
+                    const int s0 = (signsF ^ inp[1]) >> 31, s1 = (signsF ^ inp[0]) >> 31;
+                    hout[0] = (o0 ^ s0) - s0;
+                    hout[1] = (o1 ^ s1) - s1;
+                    lds_wr(ad[0], sat_sum_u8(inp[0], hout[0]));
+                    lds_wr(ad[1], sat_sum_u8(inp[1], hout[1]));
+                }
+                if (start + block < sb_end && (start >> 6) != ((start + 2 * block - 1) >> 6)) lds_barrier();
+            }
+            if (in_sb) {
+                const int xall = signsF ^ inp[0] ^ inp[1];
+                int pre[NC + 1], suf[NC + 1];
+                pre[0] = min0; suf[NC] = 127;
+#pragma unroll
+                for (int k = 0; k < NC; k++) pre[k + 1] = min(pre[k], mg[k]);
+#pragma unroll
+                for (int k = NC - 1; k >= 0; k--) suf[k] = min(suf[k + 1], mg[k]);
+#pragma unroll
+                for (int k = 2; k < NC; k++) {
+                    const int other = min(pre[k], suf[k + 1]);
+                    const int sg = (xall ^ inp[k]) >> 31;
+                    const int out = (other ^ sg) - sg;
+                    hout[k] = out;
+                    lds_wr(ad[k], sat_sum_u8(inp[k], out));
+                }
+            }
+            // the next outer block reads what this one wrote: a barrier, unless both sit inside one and the same wavefront
+            if ((sb >> 6) != ((sb + 2 * block2 - 1) >> 6)) lds_barrier();
+        }
+    }
+    int rel = (work && !lane_chain && !two_level) ? jj : 0x40000000;
+    for (int start = (lane_chain || two_level) ? kM : 0; start < kM; start += block, rel -= block) {
         if ((uint32_t)rel < (uint32_t)block) {
             if constexpr (NC == 2) {
                 // two hazard entries: each one's magnitude sent back is min(partial min0, the other's magnitude) =
@@ -779,9 +843,9 @@ __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, con
         default: break; }
 
 #define DVBS2_HAZ_CALL(D, NCV) { if constexpr (D - 2 >= NCV) { \
-        if (layer0) check_node_hazard<D, NCV, true>(lds_all, ent, jj, lb, work, block, mw, nm, 0, nullptr, htab, hb_ctr, hb_epoch, hb_lane); else check_node_hazard<D, NCV, false>(lds_all, ent, jj, lb, work, block, mw, nm, 0, nullptr, htab, hb_ctr, hb_epoch, hb_lane); } }
+        if (layer0) check_node_hazard<D, NCV, true, false, false, HZ2>(lds_all, ent, jj, lb, work, block, block2, mw, nm, 0, nullptr, htab, hb_ctr, hb_epoch, hb_lane); else check_node_hazard<D, NCV, false, false, false, HZ2>(lds_all, ent, jj, lb, work, block, block2, mw, nm, 0, nullptr, htab, hb_ctr, hb_epoch, hb_lane); } }
 #define DVBS2_HAZ_CASE(D) case D: if constexpr (D >= 4 && D <= DMAX && D > DMAX - 8) { \
-        if (nc == 2) DVBS2_HAZ_CALL((D >= 4 ? D : 4), 2) else if (nc == 4) DVBS2_HAZ_CALL((D >= 4 ? D : 4), 4) else DVBS2_HAZ_CALL((D >= 4 ? D : 4), 8) } break;
+        if (nc == 2) DVBS2_HAZ_CALL((D >= 4 ? D : 4), 2) else if (nc == 4) DVBS2_HAZ_CALL((D >= 4 ? D : 4), 4) else { if constexpr (HZ2) { if (nc == 8) DVBS2_HAZ_CALL((D >= 4 ? D : 4), 8) else DVBS2_HAZ_CALL((D >= 4 ? D : 4), 12) } else DVBS2_HAZ_CALL((D >= 4 ? D : 4), 8) } } break;
 #define DVBS2_HAZ_SWITCH switch (deg) { \
         DVBS2_HAZ_CASE(4) DVBS2_HAZ_CASE(5) DVBS2_HAZ_CASE(6) DVBS2_HAZ_CASE(7) DVBS2_HAZ_CASE(8) \
         DVBS2_HAZ_CASE(9) DVBS2_HAZ_CASE(10) DVBS2_HAZ_CASE(11) DVBS2_HAZ_CASE(12) DVBS2_HAZ_CASE(13) DVBS2_HAZ_CASE(14) \
@@ -812,7 +876,9 @@ __device__ __forceinline__ uint32_t hw_cu_index()
 }
 constexpr int kCuSlots = 16 * 8 * 2 * 16;
 
-template <int DMAX, bool TIMING, int MINW = 1, bool V2 = false, bool SOLO = false, bool CHAIN = false /*V2 = false only: the packed chain node alone*/>
+template <int DMAX, bool TIMING, int MINW = 1, bool V2 = false, bool SOLO = false, bool CHAIN = false /*V2 = false only: the packed chain node alone*/,
+          bool HZ2 = false /*heavy hazard layers: twelve ordered entries, two-level walk (check_node_hazard); a build of its own because the
+                             extra register state costs the degree classes 28 and 32 ten percent everywhere else (B11, S2X B21)*/>
 __global__ __launch_bounds__(SOLO ? kSoloThreads : kThreads, SOLO ? 4 : MINW) void ldpc_layered_kernel(
     const uint32_t* __restrict__ recs, const uint32_t* __restrict__ wrecs /*per (layer, wave) sweep records*/,
     const int8_t* __restrict__ llr_in, uint8_t* __restrict__ state,
@@ -1132,6 +1198,8 @@ __global__ __launch_bounds__(SOLO ? kSoloThreads : kThreads, SOLO ? 4 : MINW) vo
             const int nc = (int)((hdr >> 8) & 0xfu);
             uint32_t* htab = ((hdr >> 12) & 1u) ? sv : nullptr; // lane-chain scratch: the sign-vector area is idle during a sweep
             const int block = (int)(hdr >> 16);
+            int block2 = 0; // hazard layers: rows per outer block of the two-level walk (0: off)
+            if constexpr (HZ2) { if (block < kM) block2 = (int)wr[(size_t)i * RSW + 2]; }
             const bool layer0 = (i == 0);
             const int mso = i * kLayerBytes; // scalar byte offset of this layer's message records
             TSTAMP(tA);
@@ -1232,6 +1300,7 @@ struct LdpcLaunch {
     bool v2;    // the build with the packed nodes
     bool solo;  // one frame per workgroup (kSoloBuilt)
     bool chain; // plain build + packed chain node (kChainBuilt; ignored with v2, which has it anyway)
+    bool hz2;   // plain pair build with the heavy-hazard paths (kHz2Built)
     int* cu_slots;
 };
 template <int DMAX> hipError_t ldpc_variant_prepare(size_t pair_lds_bytes, size_t solo_lds_bytes);
@@ -1239,6 +1308,7 @@ template <int DMAX> void ldpc_variant_launch(const LdpcLaunch& a);
 template <int DMAX> constexpr bool kSoloBuilt = (DMAX <= 16);
 // plain builds with the packed chain node: measured SLOWER than the plain build's own lane chain (B4 107.8 k vs 109.8 k, B5 57.9 k vs
 // 62.2 k frames/s) although its ordered steps cost a third -- the node's register state hurts the rest of the kernel. Not built.
+template <int DMAX> constexpr bool kHz2Built = (DMAX >= 12);
 template <int DMAX> constexpr bool kChainBuilt = false; // 128 VGPRs: four waves per SIMD must fit while a workgroup starts
 
 #ifdef DVBS2_LDPC_INSTANTIATE
@@ -1266,6 +1336,7 @@ template <int DMAX> hipError_t ldpc_variant_prepare(size_t pair_lds_bytes, size_
         if (e == hipSuccess) e = set((const void*)ldpc_layered_kernel<DMAX, false, 1, false, false, true>, pair_lds_bytes);
         if (e == hipSuccess) e = set((const void*)ldpc_layered_kernel<DMAX, false, 1, false, true, true>, solo_lds_bytes);
     }
+    if constexpr (kHz2Built<DMAX>) if (e == hipSuccess) e = set((const void*)ldpc_layered_kernel<DMAX, false, 1, false, false, false, true>, pair_lds_bytes);
     if constexpr (kDenseBuilt<DMAX>) if (e == hipSuccess) e = set((const void*)ldpc_layered_kernel<DMAX, false, 6, false, false>, pair_lds_bytes);
     if constexpr (kTimingBuilt<DMAX>) if (e == hipSuccess) e = set((const void*)ldpc_layered_kernel<DMAX, true, 1, true, false>, pair_lds_bytes);
     return e;
@@ -1282,6 +1353,12 @@ template <int DMAX> void ldpc_variant_launch(const LdpcLaunch& a)
     if constexpr (kDenseBuilt<DMAX>) {
         if (a.dense) {
             hipLaunchKernelGGL((ldpc_layered_kernel<DMAX, false, 6, false, false>), grid, block, a.lds_bytes, a.stream, DVBS2_KARGS, nullptr, nullptr, a.dm);
+            return;
+        }
+    }
+    if constexpr (kHz2Built<DMAX>) {
+        if (a.hz2) {
+            hipLaunchKernelGGL((ldpc_layered_kernel<DMAX, false, 1, false, false, false, true>), grid, block, a.lds_bytes, a.stream, DVBS2_KARGS, nullptr, nullptr, a.dm);
             return;
         }
     }

@@ -29,9 +29,9 @@ __host__ __device__ constexpr size_t pr_lds_bytes(int N, int K) { return 2 * pr_
         else check_node<D, false, true, false>(lds_all, ent, jj, lb, mw, nm, own_in, &carry); } break;
 #define DVBS2_PR_SWITCH switch (deg) { DVBS2_PR_CASE(3) DVBS2_PR_CASE(4) DVBS2_PR_CASE(5) DVBS2_PR_CASE(6) DVBS2_PR_CASE(7) default: break; }
 #define DVBS2_PRH_CALL(D, NCV) { if constexpr (D - 2 >= NCV) { \
-        if (first_layer) check_node_hazard<D, NCV, true, true, false>(lds_all, ent, jj, lb, work, block, mw, nm, own_in, &carry, nullptr, nullptr, pr_epoch, 0); \
-        else if (last_layer) check_node_hazard<D, NCV, false, true, true>(lds_all, ent, jj, lb, work, block, mw, nm, own_in, &carry, nullptr, nullptr, pr_epoch, 0); \
-        else check_node_hazard<D, NCV, false, true, false>(lds_all, ent, jj, lb, work, block, mw, nm, own_in, &carry, nullptr, nullptr, pr_epoch, 0); } }
+        if (first_layer) check_node_hazard<D, NCV, true, true, false>(lds_all, ent, jj, lb, work, block, 0, mw, nm, own_in, &carry, nullptr, nullptr, pr_epoch, 0); \
+        else if (last_layer) check_node_hazard<D, NCV, false, true, true>(lds_all, ent, jj, lb, work, block, 0, mw, nm, own_in, &carry, nullptr, nullptr, pr_epoch, 0); \
+        else check_node_hazard<D, NCV, false, true, false>(lds_all, ent, jj, lb, work, block, 0, mw, nm, own_in, &carry, nullptr, nullptr, pr_epoch, 0); } }
 #define DVBS2_PRH_CASE(D) case D: { if (nc == 2) DVBS2_PRH_CALL(D, 2) else if (nc == 4) DVBS2_PRH_CALL(D, 4) } break;
 #define DVBS2_PRH_SWITCH switch (deg) { DVBS2_PRH_CASE(4) DVBS2_PRH_CASE(5) DVBS2_PRH_CASE(6) DVBS2_PRH_CASE(7) default: break; }
 

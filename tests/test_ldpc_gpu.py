@@ -64,11 +64,12 @@ def test_near_threshold_groups(table, amp, sigma, G):
 VARIANTS = {  # every build of the sweep kernel gives the same bits (environment overrides of the per-table policy)
     "policy": {},
     "classic": {"DVBS2_PR": "0", "DVBS2_DENSE": "0"},                                              # no parity-in-records / dense build
-    "plain": {"DVBS2_PR": "0", "DVBS2_DENSE": "0", "DVBS2_V2": "0", "DVBS2_SOLO": "0"},          # byte messages, scalar nodes, pair workgroups
-    "packed-pair": {"DVBS2_PR": "0", "DVBS2_DENSE": "0", "DVBS2_V2": "1", "DVBS2_SOLO": "0"},    # packed nodes, six-bit messages, pair workgroups
-    "plain-solo": {"DVBS2_PR": "0", "DVBS2_DENSE": "0", "DVBS2_V2": "0", "DVBS2_SOLO": "1"},     # scalar nodes, one frame per workgroup
-    "packed-solo": {"DVBS2_PR": "0", "DVBS2_DENSE": "0", "DVBS2_V2": "1", "DVBS2_SOLO": "1"},
-    "soft-barrier": {"DVBS2_PR": "0", "DVBS2_DENSE": "0", "DVBS2_V2": "1", "DVBS2_SOLO": "0", "DVBS2_SOFT_BARRIER": "1"},  # per-frame software barriers
+    "plain": {"DVBS2_PR": "0", "DVBS2_DENSE": "0", "DVBS2_HZ2": "0", "DVBS2_V2": "0", "DVBS2_SOLO": "0"},          # byte messages, scalar nodes, pair workgroups
+    "packed-pair": {"DVBS2_PR": "0", "DVBS2_DENSE": "0", "DVBS2_HZ2": "0", "DVBS2_V2": "1", "DVBS2_SOLO": "0"},    # packed nodes, six-bit messages, pair workgroups
+    "plain-solo": {"DVBS2_PR": "0", "DVBS2_DENSE": "0", "DVBS2_HZ2": "0", "DVBS2_V2": "0", "DVBS2_SOLO": "1"},     # scalar nodes, one frame per workgroup
+    "packed-solo": {"DVBS2_PR": "0", "DVBS2_DENSE": "0", "DVBS2_HZ2": "0", "DVBS2_V2": "1", "DVBS2_SOLO": "1"},
+    "heavy-hazard": {"DVBS2_PR": "0", "DVBS2_DENSE": "0", "DVBS2_HZ2": "1"},                       # twelve ordered entries, two-level walk (degree classes >= 12)
+    "soft-barrier": {"DVBS2_PR": "0", "DVBS2_DENSE": "0", "DVBS2_HZ2": "0", "DVBS2_V2": "1", "DVBS2_SOLO": "0", "DVBS2_SOFT_BARRIER": "1"},  # per-frame software barriers
 }
 
 
