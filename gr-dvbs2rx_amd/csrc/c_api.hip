@@ -10,6 +10,7 @@
 #include "bch_hip.h"
 #include "demap_hip.h"
 #include "plpayload_hip.h"
+#include "bbdeheader_hip.h"
 #include "device_guard.h"
 #include "demap_math.hpp"
 #include <algorithm>
@@ -851,6 +852,133 @@ int dvbs2_plpayload_process(dvbs2_plpayload_t* h, const float* payload, int n_fr
     if (h->pp->process_device(h->d_in, n_frames, d_hph, d_inc, h->d_cc, d_pp, h->d_out, h->stream)) return fail(DVBS2_EDEVICE, h->pp->error());
     HCHK(hipMemcpyAsync(xfecframes, h->d_out, nf * xl * 8, hipMemcpyDeviceToHost, h->stream));
     HCHK(hipStreamSynchronize(h->stream));
+    return DVBS2_OK;
+    API_CATCH
+}
+
+} // extern "C"
+
+/* ------------------------------------------------------------------ BBFRAME de-header */
+struct dvbs2_bbdeheader {
+    BbDeheaderHip* bb = nullptr;
+    uint8_t* d_in = nullptr; uint8_t* d_out = nullptr; // staging of the host entry
+    hipStream_t stream = nullptr;
+    int device = 0;
+};
+
+extern "C" {
+
+int dvbs2_bbdeheader_create_raw(dvbs2_bbdeheader_t** h, int kbch_bits, int max_frames, int device)
+{
+    API_TRY
+    if (!h) return fail(DVBS2_EINVAL, "null handle pointer");
+    *h = nullptr;
+    if (int rc = check_device(device)) return rc;
+    dvbs2_bbdeheader* o = new (std::nothrow) dvbs2_bbdeheader();
+    if (!o) return fail(DVBS2_EDEVICE, "out of memory");
+    o->device = device;
+    o->bb = new (std::nothrow) BbDeheaderHip(kbch_bits, max_frames, device);
+    if (!o->bb || !o->bb->ok()) { std::string msg = o->bb ? o->bb->error() : "out of memory"; delete o->bb; delete o; return fail(DVBS2_EINVAL, msg); }
+    *h = o;
+    return DVBS2_OK;
+    API_CATCH
+}
+
+int dvbs2_bbdeheader_create(dvbs2_bbdeheader_t** h, int standard, int framesize, int rate, int max_frames, int device)
+{
+    API_TRY
+    if (!h) return fail(DVBS2_EINVAL, "null handle pointer");
+    *h = nullptr;
+    FecInfo fi;
+    if (!get_fec_info(standard, framesize, rate, &fi)) return fail(DVBS2_EINVAL, "unsupported (standard, framesize, rate)");
+    return dvbs2_bbdeheader_create_raw(h, (int)fi.bch_k, max_frames, device); // d_kbch_bytes, d_max_dfl (:58-61)
+    API_CATCH
+}
+
+void dvbs2_bbdeheader_destroy(dvbs2_bbdeheader_t* h)
+{
+    if (!h) return;
+    DeviceGuard guard(h->device);
+    (void)hipFree(h->d_in); (void)hipFree(h->d_out);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h->bb;
+    delete h;
+}
+
+int dvbs2_bbdeheader_params(const dvbs2_bbdeheader_t* h, int* kbch_bytes, int* max_dfl_bits, int* max_out_bytes_per_frame)
+{
+    if (!h) return fail(DVBS2_EINVAL, "null handle");
+    if (kbch_bytes) *kbch_bytes = h->bb->kbch_bytes();
+    if (max_dfl_bits) *max_dfl_bits = h->bb->max_dfl();
+    if (max_out_bytes_per_frame) *max_out_bytes_per_frame = h->bb->max_out_bytes_per_frame();
+    return DVBS2_OK;
+}
+
+int dvbs2_bbdeheader_process_device(dvbs2_bbdeheader_t* h, const uint8_t* d_bbframes, int n_frames, uint8_t* d_ts_out, void* stream)
+{
+    API_TRY
+    if (!h) return fail(DVBS2_EINVAL, "null handle");
+    if (n_frames < 0 || (n_frames && (!d_bbframes || !d_ts_out))) return fail(DVBS2_EINVAL, "bad argument");
+    if (n_frames > h->bb->max_frames()) return fail(DVBS2_ESIZE, "n_frames exceeds max_frames");
+    if (h->bb->process_device(d_bbframes, n_frames, d_ts_out, (hipStream_t)stream)) return fail(DVBS2_EDEVICE, h->bb->error());
+    return DVBS2_OK;
+    API_CATCH
+}
+
+int dvbs2_bbdeheader_finish(dvbs2_bbdeheader_t* h, int64_t* produced, void* stream)
+{
+    API_TRY
+    if (!h) return fail(DVBS2_EINVAL, "null handle");
+    BbdhState st;
+    if (h->bb->state(&st, (hipStream_t)stream)) return fail(DVBS2_EDEVICE, h->bb->error());
+    if (produced) *produced = (int64_t)st.produced;
+    return DVBS2_OK;
+    API_CATCH
+}
+
+int dvbs2_bbdeheader_counters(dvbs2_bbdeheader_t* h, dvbs2_bbdeheader_counters_t* out, void* stream)
+{
+    API_TRY
+    if (!h || !out) return fail(DVBS2_EINVAL, "bad argument");
+    BbdhState st;
+    if (h->bb->state(&st, (hipStream_t)stream)) return fail(DVBS2_EDEVICE, h->bb->error());
+    out->packets = st.packets; out->errors = st.errors; out->bbframes = st.bbframes; out->dropped = st.dropped; out->gaps = st.gaps;
+    out->overruns = st.overruns; out->synched = st.synched; out->partial_ts_bytes = st.partial;
+    return DVBS2_OK;
+    API_CATCH
+}
+
+int dvbs2_bbdeheader_reset(dvbs2_bbdeheader_t* h, void* stream)
+{
+    API_TRY
+    if (!h) return fail(DVBS2_EINVAL, "null handle");
+    if (h->bb->reset((hipStream_t)stream)) return fail(DVBS2_EDEVICE, h->bb->error());
+    return DVBS2_OK;
+    API_CATCH
+}
+
+int dvbs2_bbdeheader_process(dvbs2_bbdeheader_t* h, const uint8_t* bbframes, int n_frames, uint8_t* ts_out, int64_t* produced)
+{
+    API_TRY
+    if (!h) return fail(DVBS2_EINVAL, "null handle");
+    if (n_frames < 0 || (n_frames && (!bbframes || !ts_out))) return fail(DVBS2_EINVAL, "bad argument");
+    if (n_frames > h->bb->max_frames()) return fail(DVBS2_ESIZE, "n_frames exceeds max_frames");
+    if (produced) *produced = 0;
+    DeviceGuard guard(h->device);
+    if (!guard.ok) return fail(DVBS2_EDEVICE, "hipSetDevice failed");
+    const size_t mf = h->bb->max_frames(), fb = h->bb->kbch_bytes(), ob = h->bb->max_out_bytes_per_frame();
+    if (!h->stream) HCHK(hipStreamCreate(&h->stream));
+    if (!h->d_in) HCHK(hipMalloc(&h->d_in, mf * fb));
+    if (!h->d_out) HCHK(hipMalloc(&h->d_out, mf * ob));
+    if (n_frames) HCHK(hipMemcpyAsync(h->d_in, bbframes, (size_t)n_frames * fb, hipMemcpyHostToDevice, h->stream));
+    if (h->bb->process_device(h->d_in, n_frames, h->d_out, h->stream)) return fail(DVBS2_EDEVICE, h->bb->error());
+    BbdhState st;
+    if (h->bb->state(&st, h->stream)) return fail(DVBS2_EDEVICE, h->bb->error());
+    if (st.produced > 0) {
+        HCHK(hipMemcpyAsync(ts_out, h->d_out, (size_t)st.produced, hipMemcpyDeviceToHost, h->stream));
+        HCHK(hipStreamSynchronize(h->stream));
+    }
+    if (produced) *produced = (int64_t)st.produced;
     return DVBS2_OK;
     API_CATCH
 }

@@ -1,10 +1,11 @@
-// dvbs2rx_hip_blocks.h -- host-side mirror (C++17, header only) of the three reference blocks on the FEC hot
+// dvbs2rx_hip_blocks.h -- host-side mirror (C++17, header only) of the reference blocks on the FEC hot
 // path, implemented over the C ABI of libdvbs2_fec_hip.so. Same class names, make() argument order and
 // meaning, forecast()/general_work() item accounting, getters and error behaviour as the reference:
 //
 //   gr::dvbs2rx::ldpc_decoder_bb        include/gnuradio/dvbs2rx/ldpc_decoder_bb.h:37-50, lib/ldpc_decoder_bb_impl.cc
 //   gr::dvbs2rx::bch_decoder_bb         include/gnuradio/dvbs2rx/bch_decoder_bb.h,        lib/bch_decoder_bb_impl.cc
 //   gr::dvbs2rx::xfecframe_demapper_cb  include/gnuradio/dvbs2rx/xfecframe_demapper_cb.h, lib/xfecframe_demapper_cb_impl.cc
+//   gr::dvbs2rx::bbdeheader_bb          include/gnuradio/dvbs2rx/bbdeheader_bb.h,         lib/bbdeheader_bb_impl.cc
 //
 // It deliberately does NOT depend on GNU Radio (absent from the build image): the classes expose the
 // gr::block work-function signature with plain std::vector arguments, so that the reference's *_impl classes can
@@ -170,6 +171,61 @@ private:
     int d_n_bytes = 0, d_k_bytes = 0, d_batch;
     uint64_t d_frame_cnt = 0, d_frame_error_cnt = 0;
     std::vector<int32_t> d_corr;
+};
+
+// ---------------------------------------------------------------------------------------------- BBFRAME de-header
+class bbdeheader_bb {
+public:
+    typedef std::shared_ptr<bbdeheader_bb> sptr;
+    static sptr make(dvb_standard_t standard, dvb_framesize_t framesize, dvb_code_rate_t rate, int /*debug_level*/ = 0,
+                     int batch_frames = 512, int device = 0)
+    {
+        return sptr(new bbdeheader_bb(standard, framesize, rate, batch_frames, device));
+    }
+    ~bbdeheader_bb() { dvbs2_bbdeheader_destroy(d_h); }
+    int output_multiple() const { return d_max_dfl / 8; }                                            // lib/bbdeheader_bb_impl.cc:62
+    void forecast(int noutput_items, gr_vector_int& req) const                                       // :70-75
+    {
+        req[0] = (int)std::ceil((double)noutput_items * 8 / d_max_dfl) * d_kbch_bytes;
+    }
+    // :144-264. ninput_items[0] bytes are available; whole BBFRAMEs are consumed, whole TS packets produced.
+    int general_work(int noutput_items, gr_vector_int& ninput_items, gr_vector_const_void_star& input_items, gr_vector_void_star& output_items,
+                     int* consumed)
+    {
+        const unsigned char* in = static_cast<const unsigned char*>(input_items[0]);
+        unsigned char* out = static_cast<unsigned char*>(output_items[0]);
+        const int in_bbframes = ninput_items[0] / d_kbch_bytes;
+        const int out_bbframes = (int)std::ceil((double)noutput_items * 8 / d_max_dfl);
+        const int n_bbframes = std::min(in_bbframes, out_bbframes);                                  // :157-161
+        int done = 0, produced = 0;
+        while (done < n_bbframes) {
+            const int nf = std::min(n_bbframes - done, d_batch);
+            d_stage.resize((size_t)nf * d_max_out);
+            int64_t n = 0;
+            check(dvbs2_bbdeheader_process(d_h, in + (size_t)done * d_kbch_bytes, nf, d_stage.data(), &n));
+            std::memcpy(out + produced, d_stage.data(), (size_t)n);
+            produced += (int)n; done += nf;
+        }
+        *consumed = n_bbframes * d_kbch_bytes;
+        return produced;
+    }
+    // lib/bbdeheader_bb_impl.h:89-93
+    uint64_t get_packet_count() { return counters().packets; }
+    uint64_t get_error_count() { return counters().errors; }
+    uint64_t get_bbframe_count() { return counters().bbframes; }
+    uint64_t get_bbframe_drop_count() { return counters().dropped; }
+    uint64_t get_bbframe_gap_count() { return counters().gaps; }
+
+private:
+    bbdeheader_bb(dvb_standard_t standard, dvb_framesize_t framesize, dvb_code_rate_t rate, int batch_frames, int device) : d_batch(batch_frames)
+    {
+        check(dvbs2_bbdeheader_create(&d_h, standard, framesize, rate, batch_frames, device));
+        check(dvbs2_bbdeheader_params(d_h, &d_kbch_bytes, &d_max_dfl, &d_max_out));
+    }
+    dvbs2_bbdeheader_counters_t counters() { dvbs2_bbdeheader_counters_t c; check(dvbs2_bbdeheader_counters(d_h, &c, nullptr)); return c; }
+    dvbs2_bbdeheader_t* d_h = nullptr;
+    int d_kbch_bytes = 0, d_max_dfl = 0, d_max_out = 0, d_batch;
+    std::vector<unsigned char> d_stage;
 };
 
 // ---------------------------------------------------------------------------------------------- demapper

@@ -13,7 +13,7 @@ import numpy as np
 from . import capi
 from .capi import lib, check
 
-__all__ = ["get_fec_info", "rate_id", "LdpcDecoder", "BchDecoder", "Demapper", "FecChain", "ldpc_table_info", "ldpc_layer_info",
+__all__ = ["get_fec_info", "rate_id", "LdpcDecoder", "BchDecoder", "Demapper", "FecChain", "BbDeheader", "ldpc_table_info", "ldpc_layer_info",
            "ldpc_table_names", "bb_descramble_sequence", "PlPayload",
            "pl_scrambling_rn"]
 
@@ -299,6 +299,59 @@ def pl_scrambling_rn(gold_code, n):
     rn = np.zeros(n, np.uint8)
     check(lib.dvbs2_pl_scrambling_rn(gold_code, rn.ctypes.data, n))
     return rn
+
+
+class BbDeheader:
+    """bbdeheader_bb (reference lib/bbdeheader_bb_impl.cc): descrambled BBFRAMEs in, 188-byte MPEG-TS packets out. The block's
+    state (synchronised flag, partial packet, counters) is kept in the handle between calls, as between work() calls."""
+
+    def __init__(self, standard=capi.STANDARD_DVBS2, framesize=capi.FECFRAME_NORMAL, rate="C1_2", max_frames=64, device=0,
+                 kbch_bits=None):
+        self._h = C.c_void_p()
+        if kbch_bits is not None:
+            check(lib.dvbs2_bbdeheader_create_raw(C.byref(self._h), kbch_bits, max_frames, device))
+        else:
+            check(lib.dvbs2_bbdeheader_create(C.byref(self._h), standard, framesize, rate_id(rate), max_frames, device))
+        v = [C.c_int() for _ in range(3)]
+        check(lib.dvbs2_bbdeheader_params(self._h, *v))
+        self.kbch_bytes, self.max_dfl, self.max_out_bytes_per_frame = (x.value for x in v)
+
+    def close(self):
+        if self._h:
+            lib.dvbs2_bbdeheader_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def work(self, bbframes):
+        """bbframes: (n_frames, kbch_bytes) uint8 -> the TS bytes produced (general_work's output items)."""
+        bb = np.ascontiguousarray(bbframes, dtype=np.uint8)
+        nf = bb.shape[0] if bb.ndim == 2 else bb.size // self.kbch_bytes
+        assert bb.size == nf * self.kbch_bytes
+        out = np.empty(max(nf, 1) * self.max_out_bytes_per_frame, np.uint8)
+        produced = C.c_int64()
+        check(lib.dvbs2_bbdeheader_process(self._h, bb.ctypes.data, nf, out.ctypes.data, C.byref(produced)))
+        return out[:produced.value].copy()
+
+    def work_device(self, d_bbframes, n_frames, d_ts_out, stream=0):
+        check(lib.dvbs2_bbdeheader_process_device(self._h, d_bbframes, n_frames, d_ts_out, stream))
+
+    def finish(self, stream=0):
+        produced = C.c_int64()
+        check(lib.dvbs2_bbdeheader_finish(self._h, C.byref(produced), stream))
+        return produced.value
+
+    def counters(self, stream=0):
+        c = capi.BbDeheaderCounters()
+        check(lib.dvbs2_bbdeheader_counters(self._h, C.byref(c), stream))
+        return {k: getattr(c, k) for k, _ in c._fields_}
+
+    def reset(self, stream=0):
+        check(lib.dvbs2_bbdeheader_reset(self._h, stream))
 
 
 class FecChain:

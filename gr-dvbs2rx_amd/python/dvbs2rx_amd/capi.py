@@ -32,6 +32,11 @@ class FecInfo(C.Structure):
                 ("table", C.c_char * 24)]
 
 
+class BbDeheaderCounters(C.Structure):
+    _fields_ = [("packets", C.c_uint64), ("errors", C.c_uint64), ("bbframes", C.c_uint64), ("dropped", C.c_uint64),
+                ("gaps", C.c_uint64), ("overruns", C.c_uint64), ("synched", C.c_int32), ("partial_ts_bytes", C.c_int32)]
+
+
 # every symbol include/dvbs2_fec_hip.h declares: name -> (restype, argtypes)
 _vp, _i, _ip = C.c_void_p, C.c_int, C.POINTER(C.c_int)
 SYMBOLS = {
@@ -79,6 +84,15 @@ SYMBOLS = {
     "dvbs2_plpayload_process": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "dvbs2_plpayload_process_device": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dvbs2_pl_scrambling_rn": (_i, [_i, _vp, _i]),
+    "dvbs2_bbdeheader_create": (_i, [C.POINTER(_vp), _i, _i, _i, _i, _i]),
+    "dvbs2_bbdeheader_create_raw": (_i, [C.POINTER(_vp), _i, _i, _i]),
+    "dvbs2_bbdeheader_destroy": (None, [_vp]),
+    "dvbs2_bbdeheader_params": (_i, [_vp, _ip, _ip, _ip]),
+    "dvbs2_bbdeheader_process": (_i, [_vp, _vp, _i, _vp, C.POINTER(C.c_int64)]),
+    "dvbs2_bbdeheader_process_device": (_i, [_vp, _vp, _i, _vp, _vp]),
+    "dvbs2_bbdeheader_finish": (_i, [_vp, C.POINTER(C.c_int64), _vp]),
+    "dvbs2_bbdeheader_counters": (_i, [_vp, _vp, _vp]),
+    "dvbs2_bbdeheader_reset": (_i, [_vp, _vp]),
     "dvbs2_chain_create": (_i, [C.POINTER(_vp), _i, _i, _i, _i, _i, _i, _i]),
     "dvbs2_chain_destroy": (None, [_vp]),
     "dvbs2_chain_params": (_i, [_vp, _ip, _ip]),

@@ -252,6 +252,36 @@ int dvbs2_plpayload_process_device(dvbs2_plpayload_t* h, const float* d_payload,
  * host only; n <= 33192 */
 int dvbs2_pl_scrambling_rn(int gold_code, uint8_t* rn, int n);
 
+/* ---- downstream neighbour: BBFRAME de-header, replaces bbdeheader_bb_impl::general_work (reference
+ * lib/bbdeheader_bb_impl.cc:144-264) with parse_bbheader (:77-136) and check_crc8 (:138-142, generator
+ * x^8 + x^7 + x^6 + x^4 + x^2 + 1, :55). Input: whole descrambled BBFRAMEs of kbch / 8 bytes (what dvbs2_bch_decode /
+ * dvbs2_chain_* emit with descrambling on); output: 188-byte MPEG-TS packets back to back, sync byte restored, transport
+ * error indicator set where the packet's CRC-8 fails. The block's state -- synchronised flag, the partial TS packet that
+ * continues in the next BBFRAME, the five counters -- lives in the handle and carries over from call to call exactly as it
+ * carries over between work() calls of the block; dvbs2_bbdeheader_reset() gives the block as constructed.
+ * One defined deviation: a header that passes every check but has SYNCD/8 + 1 > DFL/8 while the block re-synchronises makes
+ * the reference's unsigned byte count wrap and its loop read past the buffer (:201-202); such a BBFRAME is dropped here and
+ * counted in `overruns`.
+ * kbch_bits = fec_info.bch_k of (standard, framesize, rate); out capacity >= n_frames * max_out_bytes_per_frame. */
+typedef struct dvbs2_bbdeheader dvbs2_bbdeheader_t;
+typedef struct {
+    uint64_t packets, errors, bbframes, dropped, gaps; /* d_packet_cnt, d_error_cnt, d_bbframe_cnt, d_bbframe_drop_cnt, d_bbframe_gap_cnt */
+    uint64_t overruns;
+    int32_t synched, partial_ts_bytes;                  /* d_synched, d_partial_ts_bytes */
+} dvbs2_bbdeheader_counters_t;
+int dvbs2_bbdeheader_create(dvbs2_bbdeheader_t** h, int standard, int framesize, int rate, int max_frames, int device);
+int dvbs2_bbdeheader_create_raw(dvbs2_bbdeheader_t** h, int kbch_bits, int max_frames, int device);
+void dvbs2_bbdeheader_destroy(dvbs2_bbdeheader_t* h);
+int dvbs2_bbdeheader_params(const dvbs2_bbdeheader_t* h, int* kbch_bytes, int* max_dfl_bits, int* max_out_bytes_per_frame);
+/* host buffers; *produced = bytes written to ts_out (a multiple of 188) */
+int dvbs2_bbdeheader_process(dvbs2_bbdeheader_t* h, const uint8_t* bbframes, int n_frames, uint8_t* ts_out, int64_t* produced);
+/* device buffers, asynchronous on `stream`; the byte count of the call is read with dvbs2_bbdeheader_finish */
+int dvbs2_bbdeheader_process_device(dvbs2_bbdeheader_t* h, const uint8_t* d_bbframes, int n_frames, uint8_t* d_ts_out, void* stream);
+/* waits for the calls enqueued on `stream`; *produced = bytes written by the LAST of them */
+int dvbs2_bbdeheader_finish(dvbs2_bbdeheader_t* h, int64_t* produced, void* stream);
+int dvbs2_bbdeheader_counters(dvbs2_bbdeheader_t* h, dvbs2_bbdeheader_counters_t* out, void* stream);
+int dvbs2_bbdeheader_reset(dvbs2_bbdeheader_t* h, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -9,6 +9,7 @@
 #include <cstdint>
 #include <exception>
 #include "bch.h"
+#include "gf_util.h"
 
 using namespace gr::dvbs2rx;
 typedef bch_codec<uint32_t, bitset256_t> codec_t; // the instantiation of bch_decoder_bb_impl (lib/bch_decoder_bb_impl.h)
@@ -41,3 +42,12 @@ extern "C" int ref_bch_decode(void* p, const uint8_t* cw, uint8_t* msg)
     catch (const std::exception&) { return -2; }
 }
 extern "C" void ref_bch_encode(void* p, const uint8_t* msg, uint8_t* cw) { ((ref_bch*)p)->codec->encode(msg, cw); }
+
+// The CRC-8 check of bbdeheader_bb (lib/bbdeheader_bb_impl.cc:55-56,138-142): remainder of the byte string modulo
+// x^8 + x^7 + x^6 + x^4 + x^2 + 1 through the reference's own table and gf2_poly_rem (lib/gf_util.h:177-262).
+extern "C" int ref_crc8_rem(const uint8_t* in, int size)
+{
+    static const gf2_poly<uint16_t> poly(0b111010101);
+    static const std::array<uint16_t, 256> lut = build_gf2_poly_rem_lut(poly);
+    return (int)gf2_poly_rem(in, size, poly, lut).get_poly();
+}

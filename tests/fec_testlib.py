@@ -16,7 +16,7 @@ ORACLE_DIR = os.path.join(ROOT, "oracle")
 
 def _build_oracle():
     so = os.path.join(ORACLE_DIR, "liboracle.so")
-    srcs = [os.path.join(ORACLE_DIR, f) for f in ("ldpc_oracle.c", "bch_oracle.c", "demap_oracle.c", "bb_oracle.c", "pl_oracle.c")]
+    srcs = [os.path.join(ORACLE_DIR, f) for f in ("ldpc_oracle.c", "bch_oracle.c", "demap_oracle.c", "bb_oracle.c", "bbdeheader_oracle.c", "pl_oracle.c")]
     if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["make", "-C", ORACLE_DIR, "liboracle.so"], stdout=subprocess.DEVNULL)
     return so
@@ -61,6 +61,11 @@ def oracle():
         o.oracle_pl_rn.argtypes = [C.c_int, C.c_void_p, C.c_int]
         o.oracle_pl_payload.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_void_p, C.c_void_p]
         o.oracle_bb_descramble.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+        o.oracle_crc8_rem.argtypes = [C.c_void_p, C.c_int]
+        o.oracle_crc8_rem.restype = C.c_uint8
+        o.oracle_bbdh_init.argtypes = [C.c_void_p, C.c_int]
+        o.oracle_bbdh_work.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        o.oracle_bbdh_work.restype = C.c_longlong
         _oracle = o
     return _oracle
 
@@ -100,6 +105,7 @@ def ref_bch():
         r.ref_bch_n.argtypes = [C.c_void_p]
         r.ref_bch_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         r.ref_bch_encode.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        r.ref_crc8_rem.argtypes = [C.c_void_p, C.c_int]
         _ref_bch = r
     return _ref_bch
 
@@ -350,3 +356,90 @@ def oracle_pl_payload(payload, n_slots, has_pilots, gold, plheader_phase, fine_f
         oracle().oracle_pl_payload(ptr(payload[f]), n_slots, int(has_pilots), gold, float(plheader_phase[f]), float(fine_foffset[f]),
                                    int(coarse[f]), ptr(np.ascontiguousarray(pp[f])), ptr(out[f]))
     return out
+
+
+# ---- BBFRAME de-header (oracle/bbdeheader_oracle.c) -------------------------------------------------------------------
+class _BbdhOracleState(C.Structure):
+    _fields_ = [("kbch_bytes", C.c_int), ("max_dfl", C.c_int), ("synched", C.c_int), ("partial", C.c_int),
+                ("partial_pkt", C.c_uint8 * 188), ("packets", C.c_uint64), ("errors", C.c_uint64), ("bbframes", C.c_uint64),
+                ("dropped", C.c_uint64), ("gaps", C.c_uint64), ("overruns", C.c_uint64)]
+
+
+class OracleBbDeheader:
+    """The plain-C restatement of bbdeheader_bb (stateful like the block)."""
+
+    def __init__(self, kbch_bits):
+        self.s = _BbdhOracleState()
+        oracle().oracle_bbdh_init(C.byref(self.s), kbch_bits)
+        self.kbch_bytes = kbch_bits // 8
+        self.max_out = ((kbch_bits - 80) // 8 + 187) // 188 * 188
+
+    def work(self, bbframes):
+        bb = np.ascontiguousarray(bbframes, np.uint8)
+        nf = bb.size // self.kbch_bytes
+        out = np.empty(max(nf, 1) * self.max_out, np.uint8)
+        n = oracle().oracle_bbdh_work(C.byref(self.s), ptr(bb), nf, ptr(out))
+        return out[:n].copy()
+
+    def counters(self):
+        s = self.s
+        return dict(packets=s.packets, errors=s.errors, bbframes=s.bbframes, dropped=s.dropped, gaps=s.gaps, overruns=s.overruns,
+                    synched=s.synched, partial_ts_bytes=s.partial)
+
+
+def crc8_dvbs2(data):
+    """CRC-8 of DVB-S2 (x^8 + x^7 + x^6 + x^4 + x^2 + 1, zero start, no reflection) of a bytes-like, bit-serial."""
+    reg = 0
+    for byte in bytes(data):
+        for b in range(7, -1, -1):
+            reg = (reg << 1) | ((byte >> b) & 1)
+            if reg & 0x100:
+                reg ^= 0x1D5
+    for _ in range(8):  # append eight zero bits: remainder of data * x^8
+        reg <<= 1
+        if reg & 0x100:
+            reg ^= 0x1D5
+    return reg & 0xff
+
+
+def ts_up_stream(n_ups, rng):
+    """n_ups MPEG-TS user packets: sync byte, three zero bytes, 184 random bytes (as the reference's test builds them)."""
+    ups = rng.integers(0, 256, (n_ups, 188), dtype=np.uint8)
+    ups[:, 0] = 0x47
+    ups[:, 1:4] = 0
+    return ups.reshape(-1)
+
+
+def ts_crc_encode(up_stream):
+    """Mode adaptation: the sync byte of every user packet but the first is replaced by the CRC-8 of the preceding packet's
+    187 bytes after its sync byte (EN 302 307-1 clause 5.1.4)."""
+    s = np.array(up_stream, np.uint8).copy()
+    n = s.size // 188
+    for i in range(1, n):
+        s[i * 188] = crc8_dvbs2(s[(i - 1) * 188 + 1:i * 188])
+    return s
+
+
+def bbheader(kbch_bits, syncd_bits, dfl_bits=None, upl_bits=188 * 8, matype1=0xF2, matype2=0, sync=0x47):
+    """Ten BBHEADER bytes with a correct CRC-8: MATYPE (TS, SIS, CCM, roll-off 0.2), UPL, DFL, SYNC, SYNCD."""
+    if dfl_bits is None:
+        dfl_bits = kbch_bits - 80
+    h = bytes([matype1, matype2, upl_bits >> 8, upl_bits & 0xff, dfl_bits >> 8, dfl_bits & 0xff, sync, syncd_bits >> 8, syncd_bits & 0xff])
+    return np.frombuffer(h + bytes([crc8_dvbs2(h)]), np.uint8)
+
+
+def bbframe_stream(kbch_bits, n_frames, up_stream, syncd_bits=0):
+    """n_frames BBFRAMEs whose DATAFIELDs carry the CRC-encoded user packet stream back to back (maximum DFL); SYNCD follows
+    from where the first packet of each DATAFIELD starts."""
+    dfl_bytes = (kbch_bits - 80) // 8
+    enc = ts_crc_encode(up_stream)
+    assert enc.size >= n_frames * dfl_bytes
+    frames = np.zeros((n_frames, kbch_bits // 8), np.uint8)
+    off = 0
+    for i in range(n_frames):
+        frames[i, :10] = bbheader(kbch_bits, syncd_bits)
+        frames[i, 10:] = enc[off:off + dfl_bytes]
+        partial = (off + dfl_bytes) % 188
+        syncd_bits = ((188 - partial) % 188) * 8  # (a packet that starts with the DATAFIELD: SYNCD = 0, EN 302 307-1 clause 5.1.6)
+        off += dfl_bytes
+    return frames

@@ -1,7 +1,7 @@
 // tests/host_blocks_main.cpp -- drives the C++ host mirror (gr-dvbs2rx_amd/host/dvbs2rx_hip_blocks.h) the way a
 // GNU Radio scheduler thread would: forecast() + general_work() on byte streams read from files written by
 // tests/test_host_blocks.py, which then compares the output streams with the CPU oracle.
-//   usage: host_blocks_main <ldpc|bch|demap|loop> <in file> <out file> <framesize> <rate name> <arg>
+//   usage: host_blocks_main <ldpc|bch|bbdh|demap|loop> <in file> <out file> <framesize> <rate name> <arg>
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
@@ -43,6 +43,21 @@ int main(int argc, char** argv)
             out.resize(nout); oo[0] = out.data();
             produced = b->general_work(nout, ninput, ii, oo, &consumed);
             std::printf("frames %llu errors %llu\n", (unsigned long long)b->get_frame_count(), (unsigned long long)b->get_error_count());
+        } else if (kind == "bbdh") {
+            // bbdeheader_bb: `arg` BBFRAMEs in two general_work calls (the block's state must carry over)
+            auto b = bbdeheader_bb::make(STANDARD_DVBS2, fs, rate);
+            const int fb = (int)(in.size() / arg), first = arg / 2;
+            out.resize((size_t)arg * b->output_multiple() + 188);
+            int c = 0;
+            ninput[0] = first * fb; oo[0] = out.data();
+            produced = b->general_work(first * b->output_multiple(), ninput, ii, oo, &c);
+            consumed = c;
+            ninput[0] = (arg - first) * fb; ii[0] = in.data() + consumed; oo[0] = out.data() + produced;
+            produced += b->general_work((arg - first) * b->output_multiple(), ninput, ii, oo, &c);
+            consumed += c;
+            std::printf("packets %llu errors %llu bbframes %llu dropped %llu gaps %llu\n", (unsigned long long)b->get_packet_count(),
+                        (unsigned long long)b->get_error_count(), (unsigned long long)b->get_bbframe_count(),
+                        (unsigned long long)b->get_bbframe_drop_count(), (unsigned long long)b->get_bbframe_gap_count());
         } else if (kind == "loop") {
             // demapper -> LDPC with the llr_pdu port wired back into the demapper (apps/dvbs2-rx:853-863, 873):
             // 32 frames demapped with the pre-decoder estimate, decoded, refined; then 32 more with the refined N0.

@@ -1,0 +1,208 @@
+"""BBFRAME de-header: BBHEADER check, TS packet extraction across BBFRAMEs, per-packet CRC-8.
+
+The first seven cases restate the reference's own test file python/dvbs2rx/qa_bbdeheader_bb.py (same stream construction, same
+expected user-packet ranges); the expected bytes follow from the construction, not from running anything. They pin the oracle
+on the CPU and are then the parity cases of the HIP path, together with a fuzz over corrupted streams cut into random calls."""
+import json
+import os
+from math import ceil, floor
+
+import numpy as np
+import pytest
+
+import fec_testlib as T
+
+KBCH = 16008  # QPSK 1/4 normal, as in the reference's tests
+DFL_BYTES = (KBCH - 80) // 8
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _streams(n_bbframes, seed, syncd=0):
+    rng = np.random.default_rng(seed)
+    n_ups = int(ceil(n_bbframes * DFL_BYTES / 188))
+    ups = T.ts_up_stream(n_ups, rng)
+    return ups, T.bbframe_stream(KBCH, n_bbframes, ups, syncd)
+
+
+def _expected(ups, n_bbframes, n_discarded=0):
+    """qa_bbdeheader_bb._assert_up_stream: from the first full packet after the discarded BBFRAMEs to the last full one."""
+    i_start = int(ceil(n_discarded * DFL_BYTES / 188)) * 188
+    i_end = int(floor(n_bbframes * DFL_BYTES / 188)) * 188
+    return ups[i_start:i_end]
+
+
+def _undetectable(frames, field_off, shift):
+    """xor a multiple of the generator polynomial into a two-byte header field: the header CRC still passes."""
+    err = (0x1D5 << shift).to_bytes(2, "big")
+    f = frames.copy()
+    f[0, field_off] ^= err[0]
+    f[0, field_off + 1] ^= err[1]
+    return f
+
+
+def qa_cases():
+    """(name, bbframes, expected TS bytes) for the seven cases of qa_bbdeheader_bb.py"""
+    out = []
+    ups, fr = _streams(10, 1)
+    out.append(("successful_deframing", fr, _expected(ups, 10)))
+    ups, fr = _streams(2, 2)
+    bad = fr.copy(); bad[0, 9] ^= 255
+    out.append(("bbheader_crc_error", bad, _expected(ups, 2, 1)))
+    ups, fr = _streams(2, 3)
+    bad = _undetectable(fr, 4, 0)
+    assert ((int(bad[0, 4]) << 8) | int(bad[0, 5])) > KBCH - 80
+    out.append(("undetected_dfl_too_large", bad, _expected(ups, 2, 1)))
+    bad = _undetectable(fr, 4, 2)
+    assert (((int(bad[0, 4]) << 8) | int(bad[0, 5])) % 8) != 0
+    out.append(("undetected_dfl_not_multiple_of_8", bad, _expected(ups, 2, 1)))
+    ups, fr = _streams(2, 4)
+    bad = _undetectable(fr, 7, 7)
+    assert ((int(bad[0, 7]) << 8) | int(bad[0, 8])) > KBCH - 80
+    out.append(("undetected_syncd_corruption", bad, _expected(ups, 2, 1)))
+    # padded DATAFIELD: an integer number of packets per BBFRAME, SYNCD = 0, zero padding up to kbch
+    rng = np.random.default_rng(5)
+    n_bb, per = 4, DFL_BYTES // 188
+    dfl = per * 188
+    ups = T.ts_up_stream(n_bb * per, rng)
+    enc = T.ts_crc_encode(ups)
+    fr = np.zeros((n_bb, KBCH // 8), np.uint8)
+    for i in range(n_bb):
+        fr[i, :10] = T.bbheader(KBCH, 0, dfl * 8)
+        fr[i, 10:10 + dfl] = enc[i * dfl:(i + 1) * dfl]
+    out.append(("padded_dfl", fr, ups[:-188]))  # the last packet's CRC would only come with the next BBFRAME
+    ups, fr = _streams(10, 6, syncd=5)
+    out.append(("non_byte_aligned_syncd", fr, _expected(ups, 10, 1)))
+    # a BBFRAME missing in the middle of the stream
+    ups, fr = _streams(10, 7)
+    i_drop, bb_bytes = 5, KBCH // 8
+    n_pre = int(floor(i_drop * DFL_BYTES / 188))
+    n_dropped = int(ceil((bb_bytes + i_drop * bb_bytes - n_pre * 188) / 188))  # (the reference's own arithmetic)
+    n_post = int(floor(10 * DFL_BYTES / 188)) - n_dropped - n_pre
+    start = (n_pre + n_dropped) * 188
+    exp = np.concatenate([ups[:n_pre * 188], ups[start:start + n_post * 188]])
+    out.append(("non_consecutive_bbframes", np.delete(fr, i_drop, axis=0), exp))
+    return out
+
+
+def test_crc8_oracle_matches_reference_known_answers():
+    g = json.load(open(os.path.join(GOLD, "crc8_golden.json")))
+    assert len(g["cases"]) >= 20
+    for c in g["cases"]:
+        d = np.frombuffer(bytes.fromhex(c["hex"]), np.uint8).copy()
+        assert int(T.oracle().oracle_crc8_rem(T.ptr(d), d.size)) == c["rem"]
+        # the check value of a string = remainder of the string followed by a zero byte
+        assert T.crc8_dvbs2(d) == int(T.oracle().oracle_crc8_rem(T.ptr(np.append(d, np.uint8(0))), d.size + 1))
+
+
+def test_crc8_oracle_vs_reference_live():
+    ref = T.ref_bch()
+    if ref is None:
+        pytest.skip("oracle/_ref absent (it is built in the build container and travels prebuilt); the known answers above cover the CRC")
+    rng = np.random.default_rng(11)
+    for _ in range(2000):
+        n = int(rng.integers(1, 400))
+        d = rng.integers(0, 256, n, dtype=np.uint8)
+        assert int(T.oracle().oracle_crc8_rem(T.ptr(d), n)) == int(ref.ref_crc8_rem(T.ptr(d), n))
+
+
+@pytest.mark.parametrize("case", qa_cases(), ids=lambda c: c[0])
+def test_oracle_reference_qa_cases(case):
+    _, frames, expected = case
+    got = T.OracleBbDeheader(KBCH).work(frames)
+    assert got.size == expected.size and np.array_equal(got, expected)
+
+
+def _fuzz_stream(kbch, n_frames, seed):
+    """A long stream with everything the block reacts to: header CRC errors, invalid fields that pass the CRC, missing
+    BBFRAMEs, shortened / empty DATAFIELDs, bit errors inside packets, a SYNCD = DFL header (the defined deviation)."""
+    rng = np.random.default_rng(seed)
+    dflb = (kbch - 80) // 8
+    ups = T.ts_up_stream(int(ceil((n_frames + 2) * dflb / 188)) + 1, rng)
+    fr = T.bbframe_stream(kbch, n_frames + 2, ups)
+    keep = np.ones(n_frames + 2, bool)
+    for i in range(n_frames + 2):
+        r = rng.random()
+        if r < 0.04: fr[i, rng.integers(0, 10)] ^= 1 << rng.integers(0, 8)              # header CRC error
+        elif r < 0.07: keep[i] = False                                                   # lost BBFRAME
+        elif r < 0.10:                                                                   # short DATAFIELD (whole packets lost at the end)
+            dfl = int(rng.integers(0, dflb)) * 8
+            sy = (int(fr[i, 7]) << 8) | int(fr[i, 8])
+            fr[i, :10] = T.bbheader(kbch, min(sy, dfl), dfl)
+        elif r < 0.12: fr[i, :10] = T.bbheader(kbch, 40, 40)                             # SYNCD / 8 + 1 > DFL / 8
+        elif r < 0.14: fr[i, :10] = T.bbheader(kbch, (int(fr[i, 7]) << 8) | int(fr[i, 8]), upl_bits=187 * 8)
+        elif r < 0.16: fr[i, :10] = T.bbheader(kbch, 12)                                 # SYNCD not byte aligned
+        elif r < 0.30: fr[i, 10 + rng.integers(0, dflb)] ^= 1 << rng.integers(0, 8)     # bit error in the DATAFIELD
+    return fr[keep][:n_frames]
+
+
+def test_oracle_call_split_is_invisible():
+    fr = _fuzz_stream(KBCH, 200, 21)
+    whole = T.OracleBbDeheader(KBCH)
+    a = whole.work(fr)
+    parts = T.OracleBbDeheader(KBCH)
+    rng = np.random.default_rng(3)
+    outs, i = [], 0
+    while i < fr.shape[0]:
+        n = int(rng.integers(0, 9))
+        outs.append(parts.work(fr[i:i + n])); i += n
+    assert np.array_equal(a, np.concatenate(outs)) and whole.counters() == parts.counters()
+    c = whole.counters()
+    assert c["dropped"] > 0 and c["gaps"] > 0 and c["errors"] > 0 and c["overruns"] > 0 and c["packets"] > 1000
+
+
+# ---- the HIP path -------------------------------------------------------------------------------------------------------
+def _hip(kbch_bits, max_frames=64):
+    from dvbs2rx_amd import BbDeheader
+    return BbDeheader(kbch_bits=kbch_bits, max_frames=max_frames)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", qa_cases(), ids=lambda c: c[0])
+def test_hip_reference_qa_cases(case):
+    _, frames, expected = case
+    dev, orc = _hip(KBCH), T.OracleBbDeheader(KBCH)
+    got = dev.work(frames)
+    assert np.array_equal(got, expected)
+    assert np.array_equal(orc.work(frames), got) and dev.counters() == orc.counters()
+    dev.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kbch,seed", [(16008, 31), (3072, 32), (7032, 33), (58192, 34), (14232, 35)])
+def test_hip_fuzz_vs_oracle_with_random_call_sizes(kbch, seed):
+    fr = _fuzz_stream(kbch, 300, seed)
+    dev, orc = _hip(kbch, 32), T.OracleBbDeheader(kbch)
+    rng = np.random.default_rng(seed)
+    i = 0
+    while i < fr.shape[0]:
+        n = int(rng.integers(0, 33))
+        a, b = dev.work(fr[i:i + n]), orc.work(fr[i:i + n])
+        assert np.array_equal(a, b), f"frames {i}..{i + n}"
+        assert dev.counters() == orc.counters(), f"frames {i}..{i + n}"
+        i += n
+    assert orc.counters()["packets"] > 200
+    dev.reset()
+    assert dev.counters() == T.OracleBbDeheader(kbch).counters()
+    dev.close()
+
+
+@pytest.mark.gpu
+def test_hip_full_batch_round_trip_on_device():
+    """4096 BBFRAMEs of the 9/10 normal rate (kbch = 58192) through the device entry: every user packet comes back."""
+    import torch
+    kbch, nf = 58192, 4096
+    rng = np.random.default_rng(77)
+    dflb = (kbch - 80) // 8
+    ups = T.ts_up_stream(int(ceil(nf * dflb / 188)), rng)
+    fr = T.bbframe_stream(kbch, nf, ups)
+    dev = _hip(kbch, nf)
+    d_in = torch.from_numpy(fr).cuda()
+    d_out = torch.zeros(nf * dev.max_out_bytes_per_frame, dtype=torch.uint8, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    dev.work_device(d_in.data_ptr(), nf, d_out.data_ptr(), st)
+    n = dev.finish(st)
+    exp = ups[:int(floor(nf * dflb / 188)) * 188]
+    assert n == exp.size and np.array_equal(d_out[:n].cpu().numpy(), exp)
+    c = dev.counters(st)
+    assert c["packets"] == n // 188 and c["errors"] == 0 and c["bbframes"] == nf and c["dropped"] == 0 and c["gaps"] == 0
+    dev.close()

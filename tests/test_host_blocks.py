@@ -55,6 +55,21 @@ def test_bch_block_stream(exe, tmp_path):
     assert f"frames 8 errors {int((wret == -1).sum())}" in log
 
 
+def test_bbdeheader_block_stream(exe, tmp_path):
+    """bbdeheader_bb through the C++ mirror, in two general_work calls: TS bytes and the five counters of the block."""
+    from test_bbdeheader import _fuzz_stream
+    fi = get_fec_info(capi.STANDARD_DVBS2, capi.FECFRAME_NORMAL, "C1_4")
+    fr = _fuzz_stream(fi["bch_k"], 40, 55)
+    orc = T.OracleBbDeheader(fi["bch_k"])
+    want = orc.work(fr)
+    c = orc.counters()
+    nf = fr.shape[0]  # (the stream generator loses a few BBFRAMEs on purpose)
+    out, log = run(exe, tmp_path, "bbdh", fr, capi.FECFRAME_NORMAL, "C1_4", nf)
+    assert out.size == want.size and np.array_equal(out, want), (out.size, want.size, log)
+    assert f"packets {c['packets']} errors {c['errors']} bbframes {nf} dropped {c['dropped']} gaps {c['gaps']}" in log
+    assert f"consumed {fr.size} produced {want.size}" in log
+
+
 def test_demapper_block_stream(exe, tmp_path):
     rng = np.random.default_rng(9)
     syms = (np.exp(1j * (rng.integers(0, 4, (2, 8100)) * np.pi / 2 + np.pi / 4)) +
