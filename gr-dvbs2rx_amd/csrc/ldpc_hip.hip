@@ -300,9 +300,10 @@ LdpcDecoderHip::LdpcDecoderHip(const LdpcTableDesc* table, int out_bits_message,
     if (const char* e = getenv("DVBS2_SOLO")) solo_ = !pr_ && !dense_ && !hz2_ && dmax_ <= 16 && atoi(e) != 0;
     if (d_tdbg_) solo_ = false;
     soft_bar_ = !pr_ && !dense_ && !solo_ && dmax_ >= 20 && sched_.conflict_layers == 0; // frame barriers in software (ldpc_kernel.hpp)
-    if (const char* e = getenv("DVBS2_SOFT_BARRIER")) soft_bar_ = !pr_ && !dense_ && !solo_ && atoi(e) != 0;
+    if (const char* e = getenv("DVBS2_SOFT_BARRIER")) soft_bar_ = !pr_ && !dense_ && !solo_ && dmax_ >= 20 && atoi(e) != 0; // (built for the degree classes >= 20)
+    if (hz2_ || d_tdbg_) soft_bar_ = false;
     if (solo_) { HIP_OK(hipMalloc(&d_cu_slots_, kCuSlots * 4)); HIP_OK(hipMemset(d_cu_slots_, 0, kCuSlots * 4)); }
-    kname_ = pr_ ? std::string("ldpc_layered_pr_kernel") : "ldpc_layered_kernel<" + std::to_string(dmax_) + (dense_ ? ", dense>" : std::string(v2_ ? ", packed" : chain_plain_ ? ", chain" : "") + (solo_ ? ", solo>" : hz2_ ? ", hz2>" : ">"));
+    kname_ = pr_ ? std::string("ldpc_layered_pr_kernel") : "ldpc_layered_kernel<" + std::to_string(dmax_) + (dense_ ? ", dense>" : std::string(v2_ ? ", packed" : chain_plain_ ? ", chain" : "") + (solo_ ? ", solo>" : hz2_ ? ", hz2>" : soft_bar_ ? ", soft>" : ">"));
     lds_bytes_ = pr_ ? pr_lds_bytes(sched_.N, sched_.K) : 2 * half_lds_bytes(sched_.N);
     if (const char* e = getenv("DVBS2_LDS_PAD")) lds_bytes_ += (size_t)atoi(e); // occupancy experiments only
     if (pr_) HIP_OK(ldpc_pr_prepare(lds_bytes_));
@@ -334,7 +335,7 @@ void LdpcDecoderHip::launch_sweep(const int8_t* in, bool resume, int stop_on_goo
     la.iters = d_iters_ + fb; la.good = d_good_ + fb; la.target = resume ? d_target_ + fb : nullptr;
     la.n_frames = n_frames; la.N = sched_.N; la.K = sched_.K; la.q = sched_.q; la.cap = max_trials; la.stop_on_good = stop_on_good | (soft_bar_ ? 2 : 0);
     la.tdbg = d_tdbg_; la.lds_bytes = solo_ ? half_lds_bytes(sched_.N) : lds_bytes_; la.stream = stream; la.dense = dense_;
-    la.v2 = v2_; la.solo = solo_; la.chain = chain_plain_; la.hz2 = hz2_; la.cu_slots = d_cu_slots_;
+    la.v2 = v2_; la.solo = solo_; la.chain = chain_plain_; la.hz2 = hz2_; la.soft = soft_bar_; la.cu_slots = d_cu_slots_;
     la.dm = DemapFused{};
     if (dm && !resume) la.dm = *dm;
     if (pr_) ldpc_pr_launch(la);

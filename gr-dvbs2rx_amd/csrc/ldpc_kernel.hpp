@@ -877,7 +877,9 @@ __device__ __forceinline__ uint32_t hw_cu_index()
 constexpr int kCuSlots = 16 * 8 * 2 * 16;
 
 template <int DMAX, bool TIMING, int MINW = 1, bool V2 = false, bool SOLO = false, bool CHAIN = false /*V2 = false only: the packed chain node alone*/,
-          bool HZ2 = false /*heavy hazard layers: twelve ordered entries, two-level walk (check_node_hazard); a build of its own because the
+          bool HZ2 = false, bool SOFT = false /*SOFT: frame barriers in software -- a build of its own: the barrier state in every barrier of
+                             every build cost the 80-VGPR build 25-30 % (54 -> 199 spilled VGPRs) and the degree classes 20..32 4-10 %*/
+          /*HZ2: heavy hazard layers: twelve ordered entries, two-level walk (check_node_hazard); a build of its own because the
                              extra register state costs the degree classes 28 and 32 ten percent everywhere else (B11, S2X B21)*/>
 __global__ __launch_bounds__(SOLO ? kSoloThreads : kThreads, SOLO ? 4 : MINW) void ldpc_layered_kernel(
     const uint32_t* __restrict__ recs, const uint32_t* __restrict__ wrecs /*per (layer, wave) sweep records*/,
@@ -1014,7 +1016,7 @@ __global__ __launch_bounds__(SOLO ? kSoloThreads : kThreads, SOLO ? 4 : MINW) vo
     // Frame barriers in software (bit 1 of the flag word; pair workgroups only): worth it for high-degree tables without hazard
     // layers -- few barriers, long layers: S2X B21 +12 %, S2X B10 +10 % -- and a loss where barriers are frequent (B4 -8 %: the
     // counter costs ~300 cycles per barrier against ~30 for s_barrier). Chosen per table by the host.
-    const bool soft_bar = !SOLO && (stop_on_good & 2);
+    constexpr bool soft_bar = SOFT; // (bit 1 of the flag word is what the host sets when it launches this build)
     volatile int* hb_ctr = soft_bar ? flags + 4 : nullptr; // frame barrier counter (frame_barrier)
     int hb_epoch = 0;
     const int hb_lane = lane;
@@ -1301,6 +1303,7 @@ struct LdpcLaunch {
     bool solo;  // one frame per workgroup (kSoloBuilt)
     bool chain; // plain build + packed chain node (kChainBuilt; ignored with v2, which has it anyway)
     bool hz2;   // plain pair build with the heavy-hazard paths (kHz2Built)
+    bool soft;  // pair build (plain or packed) with software frame barriers (kSoftBuilt)
     int* cu_slots;
 };
 template <int DMAX> hipError_t ldpc_variant_prepare(size_t pair_lds_bytes, size_t solo_lds_bytes);
@@ -1309,6 +1312,7 @@ template <int DMAX> constexpr bool kSoloBuilt = (DMAX <= 16);
 // plain builds with the packed chain node: measured SLOWER than the plain build's own lane chain (B4 107.8 k vs 109.8 k, B5 57.9 k vs
 // 62.2 k frames/s) although its ordered steps cost a third -- the node's register state hurts the rest of the kernel. Not built.
 template <int DMAX> constexpr bool kHz2Built = (DMAX >= 12);
+template <int DMAX> constexpr bool kSoftBuilt = (DMAX >= 20); // pays where layers are long and barriers few (measured: S2X B10, B20, B21, B24)
 template <int DMAX> constexpr bool kChainBuilt = false; // 128 VGPRs: four waves per SIMD must fit while a workgroup starts
 
 #ifdef DVBS2_LDPC_INSTANTIATE
@@ -1337,6 +1341,10 @@ template <int DMAX> hipError_t ldpc_variant_prepare(size_t pair_lds_bytes, size_
         if (e == hipSuccess) e = set((const void*)ldpc_layered_kernel<DMAX, false, 1, false, true, true>, solo_lds_bytes);
     }
     if constexpr (kHz2Built<DMAX>) if (e == hipSuccess) e = set((const void*)ldpc_layered_kernel<DMAX, false, 1, false, false, false, true>, pair_lds_bytes);
+    if constexpr (kSoftBuilt<DMAX>) {
+        if (e == hipSuccess) e = set((const void*)ldpc_layered_kernel<DMAX, false, 1, false, false, false, false, true>, pair_lds_bytes);
+        if (e == hipSuccess) e = set((const void*)ldpc_layered_kernel<DMAX, false, 1, true, false, false, false, true>, pair_lds_bytes);
+    }
     if constexpr (kDenseBuilt<DMAX>) if (e == hipSuccess) e = set((const void*)ldpc_layered_kernel<DMAX, false, 6, false, false>, pair_lds_bytes);
     if constexpr (kTimingBuilt<DMAX>) if (e == hipSuccess) e = set((const void*)ldpc_layered_kernel<DMAX, true, 1, true, false>, pair_lds_bytes);
     return e;
@@ -1359,6 +1367,13 @@ template <int DMAX> void ldpc_variant_launch(const LdpcLaunch& a)
     if constexpr (kHz2Built<DMAX>) {
         if (a.hz2) {
             hipLaunchKernelGGL((ldpc_layered_kernel<DMAX, false, 1, false, false, false, true>), grid, block, a.lds_bytes, a.stream, DVBS2_KARGS, nullptr, nullptr, a.dm);
+            return;
+        }
+    }
+    if constexpr (kSoftBuilt<DMAX>) {
+        if (a.soft && !a.solo) {
+            if (a.v2) hipLaunchKernelGGL((ldpc_layered_kernel<DMAX, false, 1, true, false, false, false, true>), grid, block, a.lds_bytes, a.stream, DVBS2_KARGS, nullptr, nullptr, a.dm);
+            else hipLaunchKernelGGL((ldpc_layered_kernel<DMAX, false, 1, false, false, false, false, true>), grid, block, a.lds_bytes, a.stream, DVBS2_KARGS, nullptr, nullptr, a.dm);
             return;
         }
     }

@@ -262,6 +262,8 @@ def test_kernel_variant_policy(monkeypatch):
     assert name("S2_TABLE_B4", DVBS2_V2="1", DVBS2_SOLO="1") == "ldpc_layered_kernel<8, packed, solo>"
     assert name("S2_TABLE_B4", DVBS2_V2="0", DVBS2_SOLO="0") == "ldpc_layered_kernel<8>"
     assert name("S2_TABLE_B11", DVBS2_V2="1", DVBS2_SOLO="1") == "ldpc_layered_kernel<32, packed>"  # no one-frame build above 128 VGPRs
+    assert name("S2X_TABLE_B21") == "ldpc_layered_kernel<32, soft>"   # long layers, no hazard layer: per-frame software barriers
+    assert name("S2_TABLE_C10") == "ldpc_layered_kernel<28, hz2>"     # short 9/10: ten and twelve ordered entries per check
     assert name("S2_TABLE_B4", DVBS2_PR="1") == "ldpc_layered_pr_kernel"
     assert name("S2_TABLE_B1", DVBS2_PR="1") == "ldpc_layered_pr_kernel"
 
