@@ -57,3 +57,32 @@ def test_two_ranks_gloo_sharded_decode_equals_unsharded():
     assert (a0, b0, a1, b1) == (0, 32, 32, 64)
     assert h0 == T.sha(full[:32]) and h1 == T.sha(full[32:]) and ret0 + ret1 == fret
     assert dt0 == dt1 == 2.0 and f0 == f1 == 64.0
+
+
+def _worker8(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world), RANK=str(rank), LOCAL_RANK=str(rank))
+    shard.init_from_env(backend="gloo")
+    a, b = shard.shard_range(32768, world, rank, 32)   # BASELINE config 5: 32768 frames over 8 GPUs, groups of 32
+    shard.barrier_sync()
+    dt = shard.max_over_ranks(0.5 + 0.01 * rank)
+    frames = shard.sum_over_ranks(b - a)
+    q.put((rank, a, b, dt, frames))
+    shard.finalize()
+
+
+def test_eight_ranks_gloo_config5_shares():
+    """The 8-rank shape of BASELINE config 5 (bench.py --gpus 8 runs the LLR-domain chain on 4096 frames per rank): every rank gets
+    exactly 4096 frames = 128 whole groups, the ranges tile the batch, the job's time is the slowest rank's, no data collective."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker8, args=(r, 8, port, q)) for r in range(8)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=240) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for r, (rank, a, b, dt, frames) in enumerate(res):
+        assert (rank, a, b) == (r, 4096 * r, 4096 * (r + 1))
+        assert abs(dt - 0.57) < 1e-9 and frames == 32768.0
