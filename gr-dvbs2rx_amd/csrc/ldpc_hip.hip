@@ -125,7 +125,7 @@ LdpcDecoderHip::LdpcDecoderHip(const LdpcTableDesc* table, int out_bits_message,
         uint32_t nc_code = 0;
         if (L.block < 360) {
             nc_code = L.n_conflict <= 2 ? 2 : L.n_conflict <= 4 ? 4 : L.n_conflict <= 8 ? 8 : 12;
-            if (L.n_conflict > (hz2_ ? kMaxHazardHz2 : kMaxHazard) || (int)nc_code > L.cnt) nc_code = kHazardWalk;
+            if (L.n_conflict > (hz2_ && dmax_ <= kMaxHazard12Dmax ? kMaxHazardHz2 : kMaxHazard) || (int)nc_code > L.cnt) nc_code = kHazardWalk;
         }
         // A layer whose only hazard is ONE pair (two entries of one group) with a small block is walked as a lane
         // chain (check_node_hazard): the pair is ordered so that entry 0's bit of row j is entry 1's bit of row

@@ -546,6 +546,7 @@ constexpr int kLaneChainMaxDeg = 28;                                  // not ins
                                                                       // 80-VGPR parity-in-records kernel (registers)
 constexpr int kMaxHazard = 8;     // ordered entries per check in the common builds, kMaxHazardHz2 in the HZ2 builds (ldpc_layered_kernel)
 constexpr int kMaxHazardHz2 = 12;
+constexpr int kMaxHazard12Dmax = 28; // (the degree class 32 has the two-level walk only: twelve ordered entries on top of 30 edges do not fit its registers)
 constexpr int kHazardWalk = 15; // header code: too many hazard entries, fall back to the single-wave chunk walk
 template <int DEG, int NC, bool LAYER0, bool PR = false, bool LAST = false, bool TWO = false /*two-level walk compiled in*/>
 __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, const uint32_t* ent, int jj, int lb, bool work,
@@ -845,7 +846,7 @@ __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, con
 #define DVBS2_HAZ_CALL(D, NCV) { if constexpr (D - 2 >= NCV) { \
         if (layer0) check_node_hazard<D, NCV, true, false, false, HZ2>(lds_all, ent, jj, lb, work, block, block2, mw, nm, 0, nullptr, htab, hb_ctr, hb_epoch, hb_lane); else check_node_hazard<D, NCV, false, false, false, HZ2>(lds_all, ent, jj, lb, work, block, block2, mw, nm, 0, nullptr, htab, hb_ctr, hb_epoch, hb_lane); } }
 #define DVBS2_HAZ_CASE(D) case D: if constexpr (D >= 4 && D <= DMAX && D > DMAX - 8) { \
-        if (nc == 2) DVBS2_HAZ_CALL((D >= 4 ? D : 4), 2) else if (nc == 4) DVBS2_HAZ_CALL((D >= 4 ? D : 4), 4) else { if constexpr (HZ2) { if (nc == 8) DVBS2_HAZ_CALL((D >= 4 ? D : 4), 8) else DVBS2_HAZ_CALL((D >= 4 ? D : 4), 12) } else DVBS2_HAZ_CALL((D >= 4 ? D : 4), 8) } } break;
+        if (nc == 2) DVBS2_HAZ_CALL((D >= 4 ? D : 4), 2) else if (nc == 4) DVBS2_HAZ_CALL((D >= 4 ? D : 4), 4) else { if constexpr (HZ2 && DMAX <= kMaxHazard12Dmax) { if (nc == 8) DVBS2_HAZ_CALL((D >= 4 ? D : 4), 8) else DVBS2_HAZ_CALL((D >= 4 ? D : 4), 12) } else DVBS2_HAZ_CALL((D >= 4 ? D : 4), 8) } } break;
 #define DVBS2_HAZ_SWITCH switch (deg) { \
         DVBS2_HAZ_CASE(4) DVBS2_HAZ_CASE(5) DVBS2_HAZ_CASE(6) DVBS2_HAZ_CASE(7) DVBS2_HAZ_CASE(8) \
         DVBS2_HAZ_CASE(9) DVBS2_HAZ_CASE(10) DVBS2_HAZ_CASE(11) DVBS2_HAZ_CASE(12) DVBS2_HAZ_CASE(13) DVBS2_HAZ_CASE(14) \
