@@ -1327,6 +1327,11 @@ template <int DMAX> constexpr bool kTimingBuilt = (DMAX == 8);
 // only the degree class 5..12 survives 80 VGPRs (120 B of scratch); the classes of short 5/6 and 8/9 (DMAX 20, 28) spill so
 // much that they run 8x slower (measured)
 template <int DMAX> constexpr bool kDenseBuilt = (DMAX == 12);
+#ifdef DVBS2_TIMING_HZ2 // experiment builds: cycle stamps in the heavy-hazard build instead of the packed one
+#define DVBS2_TIMING_KERNEL ldpc_layered_kernel<DMAX, true, 1, false, false, false, true>
+#else
+#define DVBS2_TIMING_KERNEL ldpc_layered_kernel<DMAX, true, 1, true, false>
+#endif
 #define DVBS2_KARGS a.recs, a.wrecs, a.llr_in, a.state, a.msgs, a.iters, a.good, a.target, a.n_frames, a.N, a.K, a.q, a.cap, a.stop_on_good
 template <int DMAX> hipError_t ldpc_variant_prepare(size_t pair_lds_bytes, size_t solo_lds_bytes)
 {
@@ -1347,7 +1352,7 @@ template <int DMAX> hipError_t ldpc_variant_prepare(size_t pair_lds_bytes, size_
         if (e == hipSuccess) e = set((const void*)ldpc_layered_kernel<DMAX, false, 1, true, false, false, false, true>, pair_lds_bytes);
     }
     if constexpr (kDenseBuilt<DMAX>) if (e == hipSuccess) e = set((const void*)ldpc_layered_kernel<DMAX, false, 6, false, false>, pair_lds_bytes);
-    if constexpr (kTimingBuilt<DMAX>) if (e == hipSuccess) e = set((const void*)ldpc_layered_kernel<DMAX, true, 1, true, false>, pair_lds_bytes);
+    if constexpr (kTimingBuilt<DMAX>) if (e == hipSuccess) e = set((const void*)DVBS2_TIMING_KERNEL, pair_lds_bytes);
     return e;
 }
 template <int DMAX> void ldpc_variant_launch(const LdpcLaunch& a)
@@ -1355,7 +1360,7 @@ template <int DMAX> void ldpc_variant_launch(const LdpcLaunch& a)
     const dim3 grid((a.n_frames + 1) / 2), block(kThreads);
     if constexpr (kTimingBuilt<DMAX>) {
         if (a.tdbg) {
-            hipLaunchKernelGGL((ldpc_layered_kernel<DMAX, true, 1, true, false>), grid, block, a.lds_bytes, a.stream, DVBS2_KARGS, a.tdbg, nullptr, a.dm);
+            hipLaunchKernelGGL((DVBS2_TIMING_KERNEL), grid, block, a.lds_bytes, a.stream, DVBS2_KARGS, a.tdbg, nullptr, a.dm);
             return;
         }
     }
