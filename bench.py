@@ -96,15 +96,15 @@ def cpu_baseline(table, N, trials, one_core_s=3.0, all_core_s=6.0):
             "logical_cpus": len(os.sched_getaffinity(0))}
 
 
-def measured_traffic(kernel, frames, trials):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/traffic.json),
-    when the profiled configuration equals the one being run; None otherwise."""
+def measured_traffic(config, kernel, frames, trials):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/traffic.json <-
+    tools/gen_traffic.py), when the profiled configuration (name, kernel build, batch, cap) equals the one being run; None otherwise."""
     try:
         t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
     except Exception:
         return None
     for e in t.get("entries", []):
-        if e["kernel"] == kernel and e["frames_per_launch"] == frames and e["max_trials"] == trials:
+        if e.get("config") == config and e["kernel"] == kernel and e["frames_per_launch"] == frames and e["max_trials"] == trials:
             return e["hbm_bytes_per_launch"]
     return None
 
@@ -122,12 +122,14 @@ def timed(step, steps, warmup, shard, dev):
     return shard.max_over_ranks(time.perf_counter() - t0, device=dev)
 
 
-def roofline(obj, b_alg_ldpc, nf, traffic=None):
+def roofline(obj, b_alg_ldpc, nf, traffic=None, config=None, trials=None):
     """HIP events around the dominant kernel (the LDPC sweep) on its launch stream: algorithmic bytes of one launch / its
     average duration."""
     kern_ms, launches = obj.profile(False)
     avg_s = kern_ms / max(launches, 1) * 1e-3
     achieved = b_alg_ldpc * nf / avg_s / 1e9 if avg_s > 0 else 0.0
+    if traffic is None and config is not None:
+        traffic = measured_traffic(config, obj.kernel_name, nf, trials)
     return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic, "kernel": obj.kernel_name, "avg_launch_ms": avg_s * 1e3, "launches": launches,
             "algorithmic_bytes_per_frame": b_alg_ldpc}
@@ -233,7 +235,7 @@ def main():
     dt = timed(step, args.steps, 0, shard, dev)
     iters_mean = float((args.trials - d_ret.clamp(min=0)).float().mean().item()) if args.input != "noise" else float(args.trials)
     b_alg = ldpc_bytes(N, out_bytes, info["links_total"], args.trials if args.input == "noise" else iters_mean)
-    rl = roofline(dec, b_alg, nf, measured_traffic(dec.kernel_name, nf, args.trials) if args.input == "noise" else None)
+    rl = roofline(dec, b_alg, nf, measured_traffic("config2", dec.kernel_name, nf, args.trials) if args.input == "noise" else None)
     rl["limiter"] = "VALU pipe (half-rate min/med3/sad/add3), not HBM: DESIGN.md 3.3"
     fps = world * nf * args.steps / dt
     out = {
@@ -270,7 +272,7 @@ def main():
         bl = ldpc_bytes(ti["N"], d.out_bytes, ti["links_total"], trials)
         configs[name] = {"workload": label, "value": world * frames * steps2 / t, "unit": "frames/s",
                          "coded_gbps": world * frames * steps2 / t * ti["N"] / 1e9, "frames_per_gpu": frames, "max_trials": trials,
-                         "steps": steps2, "ms_per_step": t / steps2 * 1e3, "parity": par, "roofline": roofline(d, bl, frames)}
+                         "steps": steps2, "ms_per_step": t / steps2 * 1e3, "parity": par, "roofline": roofline(d, bl, frames, None, name, trials)}
         d.close()
 
     def llr_chain(name, rate, frames, trials, label):
@@ -290,7 +292,7 @@ def main():
         val = world * frames * steps2 / t
         configs[name] = {"workload": label, "value": val, "unit": "frames/s", "coded_gbps": val * ti["N"] / 1e9,
                          "frames_per_gpu": frames, "frames_total": world * frames, "max_trials": trials, "steps": steps2,
-                         "ms_per_step": t / steps2 * 1e3, "parity": par, "roofline": roofline(ch, bl, frames),
+                         "ms_per_step": t / steps2 * 1e3, "parity": par, "roofline": roofline(ch, bl, frames, None, name, trials),
                          "step_bytes_per_frame": b_step, "step_frac_of_hbm_peak": b_step * val / world / 1e9 / HBM_PEAK_GBS}
         ch.close()
 
@@ -327,7 +329,7 @@ def main():
                                               f"batch={nf}, noise-only symbols (every frame runs the cap; BCH sees failed frames)",
                                   "value": val, "unit": "frames/s", "coded_gbps": val * 64800 / 1e9, "frames_per_gpu": nf,
                                   "max_trials": args.trials, "steps": steps2, "ms_per_step": t / steps2 * 1e3, "parity": par,
-                                  "roofline": roofline(ch, bl, nf), "step_bytes_per_frame": b_step,
+                                  "roofline": roofline(ch, bl, nf, None, "config3", args.trials), "step_bytes_per_frame": b_step,
                                   "step_frac_of_hbm_peak": b_step * val / world / 1e9 / HBM_PEAK_GBS}
             ch.close(); del syms
         if "config4" in want:

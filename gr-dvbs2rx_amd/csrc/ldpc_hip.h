@@ -76,6 +76,7 @@ private:
     bool v2_ = false;             // the build with the packed nodes (check_node_v2 / check_node_chain_v2)
     bool chain_plain_ = false;    // plain sweep kernel with the packed register chain for single-pair hazard layers
     bool soft_bar_ = false;       // per-frame software barriers (high-degree tables without hazard layers)
+    bool pr_w1_ = false;          // parity-in-records kernel with one-dword records (check degree <= 4)
     bool hz2_ = false;            // the build with the heavy-hazard paths (ldpc_kernel.hpp, HZ2)
     bool solo_ = false;           // one frame per workgroup, complementary wave roles per CU (ldpc_kernel.hpp)
     int* d_cu_slots_ = nullptr;   // per-CU pattern counters of the solo kernels

@@ -85,7 +85,20 @@ LdpcDecoderHip::LdpcDecoderHip(const LdpcTableDesc* table, int out_bits_message,
     int degmax = 0, degmin = 1000;
     for (const LdpcLayer& L : sched_.layers) { degmax = std::max(degmax, L.cnt + 2); degmin = std::min(degmin, L.cnt + 2); }
     if (degmax > 32) { err_ = "check degree > 32 unsupported"; return; }
-    dmax_ = std::max(8, (degmax + 3) / 4 * 4);
+    // "parity in records" variant (ldpc_kernel_pr.hpp): check degree <= 7, at most 4 hazard entries per layer, and two
+    // pair workgroups must fit the 160 KB of LDS
+    // Policy (measured on MI355X, tools/pr_sweep.sh; the two variants give identical bits): every eligible short and
+    // medium table gains 12-43 % from the second workgroup per CU. On normal frames the classic kernel is as fast or
+    // faster since its hazard layers run as lane chains (B4: 109 k vs 106 k frames/s; thin-layer tables lose up to
+    // 20 % with parity-in-records). DVBS2_PR=0 / 1 overrides.
+    pr_ = degmax <= 7 && sched_.N < 64800;
+    if (const char* e = getenv("DVBS2_PR")) pr_ = degmax <= 7 && atoi(e) != 0;
+    for (const LdpcLayer& L : sched_.layers)
+        if (L.block < 360 && (L.n_conflict > 4 || (L.n_conflict > 2 ? 4 : 2) > L.cnt)) pr_ = false;
+    if (2 * pr_lds_bytes(sched_.N, sched_.K) > 160 * 1024) pr_ = false;
+    // degree class: the sweep kernel is built per multiple of four (message dwords per check); degree <= 4 tables that do not run the
+    // parity-in-records kernel (1/4 normal, S2X 2/9 normal) get the one-dword class -- they move ~4.4 TB/s with two (+8 %)
+    dmax_ = pr_ ? 8 : std::max(4, (degmax + 3) / 4 * 4);
     if (degmin < 3 || degmin <= dmax_ - 8) { err_ = "check degree spread unsupported by the kernel variants"; return; }
     words_per_check_ = dmax_ / 4;
     HIP_OK(hipSetDevice(device_));
@@ -171,17 +184,10 @@ LdpcDecoderHip::LdpcDecoderHip(const LdpcTableDesc* table, int out_bits_message,
             hr[(size_t)i * RS + 5 + 2 * k] = 360u - e.rot;
         }
     }
-    // "parity in records" variant (ldpc_kernel_pr.hpp): check degree <= 7, at most 4 hazard entries per layer, and two
-    // pair workgroups must fit the 160 KB of LDS
-    // Policy (measured on MI355X, tools/pr_sweep.sh; the two variants give identical bits): every eligible short and
-    // medium table gains 12-43 % from the second workgroup per CU. On normal frames the classic kernel is as fast or
-    // faster since its hazard layers run as lane chains (B4: 109 k vs 106 k frames/s; thin-layer tables lose up to
-    // 20 % with parity-in-records). DVBS2_PR=0 / 1 overrides.
-    pr_ = dmax_ == 8 && degmax <= 7 && sched_.N < 64800;
-    if (const char* e = getenv("DVBS2_PR")) pr_ = dmax_ == 8 && degmax <= 7 && atoi(e) != 0;
-    for (const LdpcLayer& L : sched_.layers)
-        if (L.block < 360 && (L.n_conflict > 4 || (L.n_conflict > 2 ? 4 : 2) > L.cnt)) pr_ = false;
-    if (2 * pr_lds_bytes(sched_.N, sched_.K) > 160 * 1024) pr_ = false;
+    // one-dword records (four 6-bit messages + the parity byte, ldpc_kernel_pr.hpp): check degree <= 4
+    pr_w1_ = pr_ && degmax <= 4;
+    if (const char* e = getenv("DVBS2_PR_W1")) pr_w1_ = pr_ && degmax <= 4 && atoi(e) != 0;
+    if (pr_w1_) words_per_check_ = 1;
     if (pr_) for (int i = 0; i < sched_.q; i++) hr[(size_t)i * RS] &= ~(1u << 12); // that kernel has no lane chain (80 VGPRs)
     if (pr_) {
         const int q = sched_.q;
@@ -303,11 +309,12 @@ LdpcDecoderHip::LdpcDecoderHip(const LdpcTableDesc* table, int out_bits_message,
     if (const char* e = getenv("DVBS2_SOFT_BARRIER")) soft_bar_ = !pr_ && !dense_ && !solo_ && dmax_ >= 20 && atoi(e) != 0; // (built for the degree classes >= 20)
     if (hz2_ || d_tdbg_) soft_bar_ = false;
     if (solo_) { HIP_OK(hipMalloc(&d_cu_slots_, kCuSlots * 4)); HIP_OK(hipMemset(d_cu_slots_, 0, kCuSlots * 4)); }
-    kname_ = pr_ ? std::string("ldpc_layered_pr_kernel") : "ldpc_layered_kernel<" + std::to_string(dmax_) + (dense_ ? ", dense>" : std::string(v2_ ? ", packed" : chain_plain_ ? ", chain" : "") + (solo_ ? ", solo>" : hz2_ ? ", hz2>" : soft_bar_ ? ", soft>" : ">"));
+    kname_ = pr_ ? std::string(pr_w1_ ? "ldpc_layered_pr_kernel<w1>" : "ldpc_layered_pr_kernel") : "ldpc_layered_kernel<" + std::to_string(dmax_) + (dense_ ? ", dense>" : std::string(v2_ ? ", packed" : chain_plain_ ? ", chain" : "") + (solo_ ? ", solo>" : hz2_ ? ", hz2>" : soft_bar_ ? ", soft>" : ">"));
     lds_bytes_ = pr_ ? pr_lds_bytes(sched_.N, sched_.K) : 2 * half_lds_bytes(sched_.N);
     if (const char* e = getenv("DVBS2_LDS_PAD")) lds_bytes_ += (size_t)atoi(e); // occupancy experiments only
     if (pr_) HIP_OK(ldpc_pr_prepare(lds_bytes_));
     else switch (dmax_) {
+        case 4: HIP_OK(ldpc_variant_prepare<4>(2 * half_lds_bytes(sched_.N), half_lds_bytes(sched_.N))); break;
         case 8: HIP_OK(ldpc_variant_prepare<8>(2 * half_lds_bytes(sched_.N), half_lds_bytes(sched_.N))); break;   case 12: HIP_OK(ldpc_variant_prepare<12>(2 * half_lds_bytes(sched_.N), half_lds_bytes(sched_.N))); break;
         case 16: HIP_OK(ldpc_variant_prepare<16>(2 * half_lds_bytes(sched_.N), half_lds_bytes(sched_.N))); break; case 20: HIP_OK(ldpc_variant_prepare<20>(2 * half_lds_bytes(sched_.N), half_lds_bytes(sched_.N))); break;
         case 24: HIP_OK(ldpc_variant_prepare<24>(2 * half_lds_bytes(sched_.N), half_lds_bytes(sched_.N))); break; case 28: HIP_OK(ldpc_variant_prepare<28>(2 * half_lds_bytes(sched_.N), half_lds_bytes(sched_.N))); break;
@@ -335,11 +342,12 @@ void LdpcDecoderHip::launch_sweep(const int8_t* in, bool resume, int stop_on_goo
     la.iters = d_iters_ + fb; la.good = d_good_ + fb; la.target = resume ? d_target_ + fb : nullptr;
     la.n_frames = n_frames; la.N = sched_.N; la.K = sched_.K; la.q = sched_.q; la.cap = max_trials; la.stop_on_good = stop_on_good | (soft_bar_ ? 2 : 0);
     la.tdbg = d_tdbg_; la.lds_bytes = solo_ ? half_lds_bytes(sched_.N) : lds_bytes_; la.stream = stream; la.dense = dense_;
-    la.v2 = v2_; la.solo = solo_; la.chain = chain_plain_; la.hz2 = hz2_; la.soft = soft_bar_; la.cu_slots = d_cu_slots_;
+    la.v2 = pr_ ? pr_w1_ : v2_; la.solo = solo_; la.chain = chain_plain_; la.hz2 = hz2_; la.soft = soft_bar_; la.cu_slots = d_cu_slots_;
     la.dm = DemapFused{};
     if (dm && !resume) la.dm = *dm;
     if (pr_) ldpc_pr_launch(la);
     else switch (dmax_) {
+        case 4: ldpc_variant_launch<4>(la); break;
         case 8: ldpc_variant_launch<8>(la); break;   case 12: ldpc_variant_launch<12>(la); break;
         case 16: ldpc_variant_launch<16>(la); break; case 20: ldpc_variant_launch<20>(la); break;
         case 24: ldpc_variant_launch<24>(la); break; case 28: ldpc_variant_launch<28>(la); break;

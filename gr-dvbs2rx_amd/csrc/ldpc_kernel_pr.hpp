@@ -12,6 +12,10 @@
 // Layout per workgroup: [half 0 LLRs][half 1 LLRs][sign vectors, shared by the halves][flags 0][flags 1].
 // Message record of (layer i, row j): 2 dwords = message bytes 0..deg-1, byte 7 = parity LLR P[i-1][j] as left by
 // layer i (offset binary); record 0 byte 7 is unused.
+// W1 (tables of check degree <= 4): ONE dword per record -- four messages as 6-bit fields (the stored message is clamped to
+// [-32, 31], R7: value + 32 in bits 6k .. 6k+5) and the parity LLR in byte 3. These tables move 8 bytes per check and layer each way
+// for 4-5 useful ones and run at ~4.9 TB/s of real traffic (short 1/4: 2.3 x the algorithmic bytes): halving the record is worth
+// the ~18 VALU instructions of the conversion around the node.
 #pragma once
 #include "ldpc_kernel.hpp"
 #include <cstdio>
@@ -35,8 +39,24 @@ __host__ __device__ constexpr size_t pr_lds_bytes(int N, int K) { return 2 * pr_
 #define DVBS2_PRH_CASE(D) case D: { if (nc == 2) DVBS2_PRH_CALL(D, 2) else if (nc == 4) DVBS2_PRH_CALL(D, 4) } break;
 #define DVBS2_PRH_SWITCH switch (deg) { DVBS2_PRH_CASE(4) DVBS2_PRH_CASE(5) DVBS2_PRH_CASE(6) DVBS2_PRH_CASE(7) default: break; }
 
+// 6-bit record <-> the byte format the check nodes take (mw[0] = four offset-binary message bytes, byte 3 of mw[1] = parity LLR)
+__device__ __forceinline__ void pr_w1_expand(uint32_t x, uint32_t* mw)
+{
+    const uint32_t f0 = x & 0x3fu, f1 = (x >> 6) & 0x3fu, f2 = (x >> 12) & 0x3fu, f3 = (x >> 18) & 0x3fu;
+    mw[0] = ((f0 | (f1 << 8)) | ((f2 | (f3 << 8)) << 16)) + 0x60606060u; // field = m + 32, byte = m + 128
+    mw[1] = (x & 0xff000000u) | 0x00808080u;
+}
+__device__ __forceinline__ uint32_t pr_w1_compress(const uint32_t* nm)
+{
+    // byte = m + 128 with m in [-32, 31] (R7), i.e. 0x60 .. 0x9f: field = m + 32 = (byte & 0x3f) ^ 0x20 (no borrow between bytes; a
+    // byte the node left unset, 0x00 or 0x80, becomes the zero message)
+    const uint32_t y = (nm[0] & 0x3f3f3f3fu) ^ 0x20202020u;
+    return (y & 0x3fu) | ((y >> 2) & 0xfc0u) | ((y >> 4) & 0x3f000u) | ((y >> 6) & 0xfc0000u) | (nm[1] & 0xff000000u);
+}
+
 // Records use the PR LDS layout: data entries as in the classic kernel; own parity of the last layer at K + j;
 // previous parity of layer 0 at K + (j + 359) mod 360 (S0 = K + 359, thr = 1).
+template <bool W1>
 __global__ __launch_bounds__(kThreads, 6) void ldpc_layered_pr_kernel(
     const uint32_t* __restrict__ recs, const int8_t* __restrict__ llr_in, uint8_t* __restrict__ state,
     uint32_t* __restrict__ msgs, int* __restrict__ iters, int* __restrict__ good, const int* __restrict__ target,
@@ -49,7 +69,8 @@ __global__ __launch_bounds__(kThreads, 6) void ldpc_layered_pr_kernel(
         if (!ta && !tb) return;
     }
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_all[];
-    constexpr int DMAX = 8, RS = rec_stride(DMAX), MW = 2;
+    constexpr int DMAX = 8, RS = rec_stride(DMAX), MW = 2 /*words the check nodes take*/, RW = W1 ? 1 : 2 /*words per stored record*/;
+    constexpr int PW = RW - 1; // word of a record whose top byte is the parity LLR
     const int half = __builtin_amdgcn_readfirstlane(threadIdx.x >= kHalf ? 1 : 0);
     const int tid = threadIdx.x - half * kHalf;
     const int lb_rel = half * (int)pr_half_bytes(K);
@@ -66,7 +87,7 @@ __global__ __launch_bounds__(kThreads, 6) void ldpc_layered_pr_kernel(
     const bool active = tid < kM;
     const int row = tid < kM ? tid : kM - 1; // threads 360..383 mirror row 359 (ldpc_kernel.hpp)
 
-    uint32_t* msg_base = msgs + (size_t)(have_frame ? f : 0) * q * MW * kMsgStride;
+    uint32_t* msg_base = msgs + (size_t)(have_frame ? f : 0) * q * RW * kMsgStride;
     int it = 0, tgt = 0;
     int pr_epoch = 0; // this kernel keeps the hardware barrier (check_node_hazard takes a frame-barrier state)
     bool finished = !have_frame;
@@ -84,12 +105,17 @@ __global__ __launch_bounds__(kThreads, 6) void ldpc_layered_pr_kernel(
                 // parity[q*j + i] = P[i][j] (layered_decoder.hh:150-152): row q-1 to LDS, row i < q-1 to byte 7 of
                 // record i+1; all message bytes start at offset-binary zero (bnl = 0, layered_decoder.hh:27-31)
                 const int8_t* pj = src + K + (size_t)q * tid;
+                if constexpr (W1) {
+                    msg_base[tid] = 0x80820820u; // four zero messages (field value 32), parity byte unused in record 0
+                    for (int i = 0; i < q - 1; i++) msg_base[(i + 1) * kMsgStride + tid] = 0x00820820u | ((uint32_t)((uint8_t)pj[i] ^ 0x80u) << 24);
+                } else {
                 msg_base[0 * kMsgStride + tid] = 0x80808080u;
                 msg_base[1 * kMsgStride + tid] = 0x80808080u;
                 for (int i = 0; i < q - 1; i++) {
                     const uint32_t b = (uint8_t)pj[i] ^ 0x80u;
                     msg_base[((i + 1) * MW + 0) * kMsgStride + tid] = 0x80808080u;
                     msg_base[((i + 1) * MW + 1) * kMsgStride + tid] = 0x00808080u | (b << 24);
+                }
                 }
                 lds[K + tid] = (uint8_t)pj[q - 1] ^ 0x80u;
             }
@@ -120,8 +146,8 @@ __global__ __launch_bounds__(kThreads, 6) void ldpc_layered_pr_kernel(
             uint32_t x = 0, z = 0;
             for (int k = 0; k < deg; k++) {
                 uint32_t v;
-                if (k == deg - 2 && i0 != q - 1) v = msg_base[((i0 + 1) * MW + 1) * kMsgStride + tid] >> 24;       // own parity P[i0]
-                else if (k == deg - 1 && i0 != 0) v = msg_base[(i0 * MW + 1) * kMsgStride + tid] >> 24;           // previous parity P[i0-1]
+                if (k == deg - 2 && i0 != q - 1) v = msg_base[((i0 + 1) * RW + PW) * kMsgStride + tid] >> 24;       // own parity P[i0]
+                else if (k == deg - 1 && i0 != 0) v = msg_base[(i0 * RW + PW) * kMsgStride + tid] >> 24;           // previous parity P[i0-1]
                 else {
                     const int a0 = tid + (int)rec[4 + 2 * k] - ((uint32_t)tid < rec[5 + 2 * k] ? 0 : kM);
                     v = lds[a0];
@@ -148,7 +174,7 @@ __global__ __launch_bounds__(kThreads, 6) void ldpc_layered_pr_kernel(
                         if (active) {
                             if (g < NGD) v = lds[kM * g + tid];
                             else if (g == NG - 1) v = lds[K + tid];
-                            else v = msg_base[((g - NGD + 1) * MW + 1) * kMsgStride + tid] >> 24; // parity row g - NGD
+                            else v = msg_base[((g - NGD + 1) * RW + PW) * kMsgStride + tid] >> 24; // parity row g - NGD
                         }
                         const unsigned long long neg = __ballot(v < 0x80u);
                         zero_any |= __ballot(v == 0x80u);
@@ -199,11 +225,11 @@ __global__ __launch_bounds__(kThreads, 6) void ldpc_layered_pr_kernel(
 
         // ---- one update sweep ----
         const bool work = !finished;
-        uint32_t pre1[MW], pre2[MW]; // records of the next two layers for this row
+        uint32_t pre1[RW], pre2[RW]; // records of the next two layers for this row
         int carry = 0x80;
         if (work) {
 #pragma unroll
-            for (int w = 0; w < MW; w++) { pre1[w] = msg_base[w * kMsgStride + row]; pre2[w] = msg_base[(MW + w) * kMsgStride + row]; }
+            for (int w = 0; w < RW; w++) { pre1[w] = msg_base[w * kMsgStride + row]; pre2[w] = msg_base[(RW + w) * kMsgStride + row]; }
         }
         uint32_t nhdr = recs[0];
         uint32_t nent[2 * DMAX];
@@ -224,26 +250,30 @@ __global__ __launch_bounds__(kThreads, 6) void ldpc_layered_pr_kernel(
             const int nc = (int)((hdr >> 8) & 0xfu);
             const int block = (int)(hdr >> 16);
             const bool first_layer = (i == 0), last_layer = (i == q - 1);
-            uint32_t* mp = msg_base + (size_t)i * MW * kMsgStride;
+            uint32_t* mp = msg_base + (size_t)i * RW * kMsgStride;
             if (hdr & 0x8000u) __syncthreads();
             const int jj = row;
             uint32_t mw[MW], nm[MW];
+            if constexpr (W1) {
+                if (work) pr_w1_expand(pre1[0], mw); else { mw[0] = 0x80808080u; mw[1] = 0x80808080u; }
+                pre1[0] = pre2[0];
+            } else {
 #pragma unroll
-            for (int w = 0; w < MW; w++) { mw[w] = work ? pre1[w] : 0x80808080u; pre1[w] = pre2[w]; }
-            const int own_in = (int)(pre1[1] >> 24); // byte 7 of record i+1 = P[i] (not used by the last layer)
+                for (int w = 0; w < MW; w++) { mw[w] = work ? pre1[w] : 0x80808080u; pre1[w] = pre2[w]; }
+            }
+            const int own_in = (int)(pre1[PW] >> 24); // top byte of record i+1 = P[i] (not used by the last layer)
             if (work && i + 2 < q) {
 #pragma unroll
-                for (int w = 0; w < MW; w++) pre2[w] = mp[(2 * MW + w) * kMsgStride + row];
+                for (int w = 0; w < RW; w++) pre2[w] = mp[(2 * RW + w) * kMsgStride + row];
             }
             if (block >= kM) {
-                if (work) {
-                    DVBS2_PR_SWITCH
-#pragma unroll
-                    for (int w = 0; w < MW; w++) mp[w * kMsgStride + jj] = nm[w];
-                }
+                if (work) { DVBS2_PR_SWITCH }
             } else {
                 DVBS2_PRH_SWITCH
-                if (work) {
+            }
+            if (work) {
+                if constexpr (W1) mp[jj] = pr_w1_compress(nm);
+                else {
 #pragma unroll
                     for (int w = 0; w < MW; w++) mp[w * kMsgStride + jj] = nm[w];
                 }
@@ -258,7 +288,7 @@ __global__ __launch_bounds__(kThreads, 6) void ldpc_layered_pr_kernel(
         uint8_t* dst = state + (size_t)f * N;
         for (int c = tid; c < K / 8; c += kHalf) reinterpret_cast<uint2*>(dst)[c] = *reinterpret_cast<const uint2*>(lds + 8 * c);
         if (active) {
-            for (int i = 0; i < q - 1; i++) dst[K + kM * i + tid] = (uint8_t)(msg_base[((i + 1) * MW + 1) * kMsgStride + tid] >> 24);
+            for (int i = 0; i < q - 1; i++) dst[K + kM * i + tid] = (uint8_t)(msg_base[((i + 1) * RW + PW) * kMsgStride + tid] >> 24);
             dst[K + kM * (q - 1) + tid] = lds[K + tid];
         }
     }
@@ -267,23 +297,26 @@ __global__ __launch_bounds__(kThreads, 6) void ldpc_layered_pr_kernel(
 #endif // DVBS2_LDPC_INSTANTIATE_PR
 
 hipError_t ldpc_pr_prepare(size_t lds_bytes);
-void ldpc_pr_launch(const LdpcLaunch& a);
+void ldpc_pr_launch(const LdpcLaunch& a); // a.v2 = one-dword records (check degree <= 4)
 
 #ifdef DVBS2_LDPC_INSTANTIATE_PR
 hipError_t ldpc_pr_prepare(size_t lds_bytes)
 {
-    hipError_t e = hipFuncSetAttribute((const void*)ldpc_layered_pr_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    hipError_t e = hipFuncSetAttribute((const void*)ldpc_layered_pr_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ldpc_layered_pr_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e == hipSuccess && getenv("DVBS2_OCC")) {
         int nb = -1;
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, ldpc_layered_pr_kernel, kThreads, lds_bytes);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, ldpc_layered_pr_kernel<false>, kThreads, lds_bytes);
         fprintf(stderr, "[pr kernel] lds %zu bytes, occupancy API: %d workgroups per CU\n", lds_bytes, nb);
     }
     return e;
 }
 void ldpc_pr_launch(const LdpcLaunch& a)
 {
-    hipLaunchKernelGGL(ldpc_layered_pr_kernel, dim3((a.n_frames + 1) / 2), dim3(kThreads), a.lds_bytes, a.stream, a.recs, a.llr_in, a.state, a.msgs,
-                       a.iters, a.good, a.target, a.n_frames, a.N, a.K, a.q, a.cap, a.stop_on_good);
+    if (a.v2) hipLaunchKernelGGL(ldpc_layered_pr_kernel<true>, dim3((a.n_frames + 1) / 2), dim3(kThreads), a.lds_bytes, a.stream, a.recs, a.llr_in, a.state, a.msgs,
+                                 a.iters, a.good, a.target, a.n_frames, a.N, a.K, a.q, a.cap, a.stop_on_good);
+    else hipLaunchKernelGGL(ldpc_layered_pr_kernel<false>, dim3((a.n_frames + 1) / 2), dim3(kThreads), a.lds_bytes, a.stream, a.recs, a.llr_in, a.state, a.msgs,
+                            a.iters, a.good, a.target, a.n_frames, a.N, a.K, a.q, a.cap, a.stop_on_good);
 }
 #endif
 

@@ -63,6 +63,7 @@ def test_near_threshold_groups(table, amp, sigma, G):
 
 VARIANTS = {  # every build of the sweep kernel gives the same bits (environment overrides of the per-table policy)
     "policy": {},
+    "pr-byte-records": {"DVBS2_PR_W1": "0"},                                                       # parity in records with two-dword records also for degree <= 4
     "classic": {"DVBS2_PR": "0", "DVBS2_DENSE": "0"},                                              # no parity-in-records / dense build
     "plain": {"DVBS2_PR": "0", "DVBS2_DENSE": "0", "DVBS2_HZ2": "0", "DVBS2_V2": "0", "DVBS2_SOLO": "0"},          # byte messages, scalar nodes, pair workgroups
     "packed-pair": {"DVBS2_PR": "0", "DVBS2_DENSE": "0", "DVBS2_HZ2": "0", "DVBS2_V2": "1", "DVBS2_SOLO": "0"},    # packed nodes, six-bit messages, pair workgroups
@@ -254,18 +255,21 @@ def test_kernel_variant_policy(monkeypatch):
     assert name("S2_TABLE_B7") == expect("S2_TABLE_B7", 16)
     assert name("S2_TABLE_B11") == expect("S2_TABLE_B11", 32)
     assert name("S2X_TABLE_B9") == expect("S2X_TABLE_B9", 16)
-    assert name("S2_TABLE_C1") == "ldpc_layered_pr_kernel"        # short / medium frames of degree <= 7: parity in records
-    assert name("S2X_TABLE_C9") == "ldpc_layered_pr_kernel"       # medium frame
+    assert name("S2_TABLE_C2") == "ldpc_layered_pr_kernel"        # short / medium frames of degree <= 7: parity in records
+    assert name("S2_TABLE_C1") == "ldpc_layered_pr_kernel<w1>"    # ... of degree <= 4: one-dword records (6-bit messages + parity byte)
+    assert name("S2_TABLE_C1", DVBS2_PR_W1="0") == "ldpc_layered_pr_kernel"
+    assert name("S2X_TABLE_C9") == "ldpc_layered_pr_kernel<w1>"   # medium frame
     assert name("S2_TABLE_C5") == "ldpc_layered_kernel<12, dense>"  # short 3/5: 16 of 18 layers are hazard layers
     assert name("S2_TABLE_C5", DVBS2_DENSE="0", DVBS2_V2="0", DVBS2_SOLO="0") == "ldpc_layered_kernel<12>"
-    assert name("S2_TABLE_C1", DVBS2_PR="0", DVBS2_V2="0", DVBS2_SOLO="0") == "ldpc_layered_kernel<8>"
+    assert name("S2_TABLE_C1", DVBS2_PR="0", DVBS2_V2="0", DVBS2_SOLO="0") == "ldpc_layered_kernel<4>"  # degree <= 4: one message dword per check
+    assert name("S2_TABLE_B1") == "ldpc_layered_kernel<4>"
     assert name("S2_TABLE_B4", DVBS2_V2="1", DVBS2_SOLO="1") == "ldpc_layered_kernel<8, packed, solo>"
     assert name("S2_TABLE_B4", DVBS2_V2="0", DVBS2_SOLO="0") == "ldpc_layered_kernel<8>"
     assert name("S2_TABLE_B11", DVBS2_V2="1", DVBS2_SOLO="1") == "ldpc_layered_kernel<32, packed>"  # no one-frame build above 128 VGPRs
     assert name("S2X_TABLE_B21") == "ldpc_layered_kernel<32, soft>"   # long layers, no hazard layer: per-frame software barriers
     assert name("S2_TABLE_C10") == "ldpc_layered_kernel<28, hz2>"     # short 9/10: ten and twelve ordered entries per check
     assert name("S2_TABLE_B4", DVBS2_PR="1") == "ldpc_layered_pr_kernel"
-    assert name("S2_TABLE_B1", DVBS2_PR="1") == "ldpc_layered_pr_kernel"
+    assert name("S2_TABLE_B1", DVBS2_PR="1") == "ldpc_layered_pr_kernel<w1>"
 
 
 @pytest.mark.parametrize("table,nf,trials,amp,sigma", [("S2_TABLE_B4", 4096, 50, 6, 4.6), ("S2_TABLE_C1", 16384, 25, 5, 4.0)])
