@@ -54,6 +54,64 @@ __device__ __forceinline__ uint32_t pr_w1_compress(const uint32_t* nm)
     return (y & 0x3fu) | ((y >> 2) & 0xfc0u) | ((y >> 4) & 0x3f000u) | ((y >> 6) & 0xfc0000u) | (nm[1] & 0xff000000u);
 }
 
+// check_node<DEG, LAYER0, PR = true, LAST> (ldpc_kernel.hpp) on the one-dword record itself: messages come out of and go back into
+// the 6-bit fields without the detour through byte words (two instructions per message each way instead of ~4.5).
+template <int DEG, bool LAYER0, bool LAST>
+__device__ __forceinline__ uint32_t check_node_pr6(uint8_t* __restrict__ lds, const uint32_t* ent, int jj, int lb, uint32_t x /*this layer's record*/,
+                                                   int own_in, int* carry)
+{
+    static_assert(DEG >= 3 && DEG <= 4, "one-dword records hold four messages");
+    constexpr bool OWN_REG = !LAST, PREV_REG = !LAYER0;
+    __builtin_amdgcn_s_setprio(0);
+    int ad[DEG], Lb[DEG];
+    const int jjb = jj + lb, jjb360 = jjb - kM;
+#pragma unroll
+    for (int k = 0; k < DEG; k++) {
+        if (k >= DEG - 2 && !(LAYER0 && k == DEG - 1)) ad[k] = jjb + (int)ent[2 * k];
+        else ad[k] = wrap_addr(jj, jjb, jjb360, ent[2 * k], ent[2 * k + 1]);
+    }
+#pragma unroll
+    for (int k = 0; k < DEG; k++) {
+        if (OWN_REG && k == DEG - 2) Lb[k] = own_in;
+        else if (PREV_REG && k == DEG - 1) Lb[k] = *carry;
+        else Lb[k] = lds_rd(ad[k]);
+    }
+    const bool last_valid = !LAYER0 || jj != 0;
+    int spare = 0x80;
+    int inp[DEG], mg[DEG];
+    int min0 = 127, min1 = 127, signs = 0;
+#pragma unroll
+    for (int k = 0; k < DEG; k++) {
+        const int mb = (int)((x >> (6 * k)) & 0x3fu) + 96; // field = m + 32 -> offset-binary byte m + 128
+        int d = min(max(Lb[k] - mb, -128), 127);
+        int mag = mag_raw(Lb[k], mb);
+        if (LAYER0 && k == DEG - 1) { d = last_valid ? d : 0; mag = last_valid ? mag : kMagAbsent; }
+        inp[k] = d; mg[k] = mag;
+        signs ^= d;
+    }
+    __builtin_amdgcn_s_setprio(1);
+    two_smallest<DEG>(mg, min0, min1);
+    min0 = clamp_mag(min0); min1 = clamp_mag(min1);
+    const int s01 = min0 + min1;
+    uint32_t y = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        if (k < DEG) {
+            const int other = s01 - vmed3_i32(mg[k], min0, min1);
+            const int sg = (signs ^ inp[k]) >> 31;
+            const int out = (other ^ sg) - sg;
+            const int nl = sat_sum_u8(inp[k], out);
+            if (OWN_REG && k == DEG - 2) *carry = nl;
+            else if (PREV_REG && k == DEG - 1) spare = nl;
+            else if (!(LAYER0 && k == DEG - 1) || last_valid) lds_wr(ad[k], nl);
+            const uint32_t f = (uint32_t)(min(max(out, -32), 31) + 32); // R7, as a field
+            y = k == 0 ? f : (f << (6 * k)) | y;
+        } else y |= 32u << (6 * k); // no such link: the zero message
+    }
+    __builtin_amdgcn_s_setprio(3);
+    return y | ((uint32_t)spare << 24);
+}
+
 // Records use the PR LDS layout: data entries as in the classic kernel; own parity of the last layer at K + j;
 // previous parity of layer 0 at K + (j + 359) mod 360 (S0 = K + 359, thr = 1).
 template <bool W1>
@@ -254,8 +312,10 @@ __global__ __launch_bounds__(kThreads, 6) void ldpc_layered_pr_kernel(
             if (hdr & 0x8000u) __syncthreads();
             const int jj = row;
             uint32_t mw[MW], nm[MW];
+            uint32_t x6 = 0;
             if constexpr (W1) {
-                if (work) pr_w1_expand(pre1[0], mw); else { mw[0] = 0x80808080u; mw[1] = 0x80808080u; }
+                x6 = pre1[0];
+                mw[0] = 0x80808080u; mw[1] = 0x80808080u; // (hazard layers expand the record below)
                 pre1[0] = pre2[0];
             } else {
 #pragma unroll
@@ -266,13 +326,24 @@ __global__ __launch_bounds__(kThreads, 6) void ldpc_layered_pr_kernel(
 #pragma unroll
                 for (int w = 0; w < RW; w++) pre2[w] = mp[(2 * RW + w) * kMsgStride + row];
             }
+            uint32_t y6 = 0;
+            bool have_y6 = false;
             if (block >= kM) {
-                if (work) { DVBS2_PR_SWITCH }
+                if constexpr (W1) {
+                    if (work) { // (the record still sits in pre-expansion form in x6)
+                        have_y6 = true;
+                        if (deg == 4) { if (first_layer) y6 = check_node_pr6<4, true, false>(lds_all, ent, jj, lb, x6, own_in, &carry); else if (last_layer) y6 = check_node_pr6<4, false, true>(lds_all, ent, jj, lb, x6, own_in, &carry); else y6 = check_node_pr6<4, false, false>(lds_all, ent, jj, lb, x6, own_in, &carry); }
+                        else { if (first_layer) y6 = check_node_pr6<3, true, false>(lds_all, ent, jj, lb, x6, own_in, &carry); else if (last_layer) y6 = check_node_pr6<3, false, true>(lds_all, ent, jj, lb, x6, own_in, &carry); else y6 = check_node_pr6<3, false, false>(lds_all, ent, jj, lb, x6, own_in, &carry); }
+                    }
+                } else {
+                    if (work) { DVBS2_PR_SWITCH }
+                }
             } else {
+                if constexpr (W1) { if (work) pr_w1_expand(x6, mw); }
                 DVBS2_PRH_SWITCH
             }
             if (work) {
-                if constexpr (W1) mp[jj] = pr_w1_compress(nm);
+                if constexpr (W1) mp[jj] = have_y6 ? y6 : pr_w1_compress(nm);
                 else {
 #pragma unroll
                     for (int w = 0; w < MW; w++) mp[w * kMsgStride + jj] = nm[w];
