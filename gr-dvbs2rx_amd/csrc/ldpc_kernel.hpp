@@ -1040,7 +1040,10 @@ __global__ __launch_bounds__(SOLO ? kSoloThreads : kThreads, SOLO ? 4 : MINW) vo
     // measured (table B4, 4096 frames): 107 k frames/s with byte messages, 93 k with six-bit fields at the same traffic (dword accesses
     // only), 85-91 k with the traffic actually reduced by a quarter: the unpacking costs more than the bytes bring -- the regular layers
     // are limited by VALU issue and memory traffic at the same time. Kept behind this switch, off.
-    constexpr bool P6 = false;
+#ifndef DVBS2_P6
+#define DVBS2_P6 0
+#endif
+    constexpr bool P6 = DVBS2_P6 != 0;
     auto msg_load = [&](uint32_t* dst, int soff, int r4, bool packed, int dg) {
 #pragma unroll
         for (int w = 0; w < MW; w++) {
