@@ -206,3 +206,48 @@ def test_hip_full_batch_round_trip_on_device():
     c = dev.counters(st)
     assert c["packets"] == n // 188 and c["errors"] == 0 and c["bbframes"] == nf and c["dropped"] == 0 and c["gaps"] == 0
     dev.close()
+
+
+@pytest.mark.gpu
+def test_bch_descramble_deheader_on_device():
+    """Two neighbouring stages back to back in HBM: BCH decode with the BB descrambler fused (dvbs2_bch_*) -> BBFRAME de-header
+    (dvbs2_bbdeheader_*). TS packets -> CRC-8 encoded BBFRAMEs -> BB scrambling -> BCH codewords with up to t bit errors (plus two
+    codewords beyond t, whose BBFRAMEs arrive damaged) -> device -> the packets come back; what comes back equals the CPU oracles' output."""
+    import torch
+    from dvbs2rx_amd import BchDecoder, BbDeheader, capi, get_fec_info
+    fi = get_fec_info(capi.STANDARD_DVBS2, capi.FECFRAME_SHORT, "C1_2")  # BCH(7200, 7032, 12)
+    kbch, nf = fi["bch_k"], 64
+    rng = np.random.default_rng(2024)
+    dflb = (kbch - 80) // 8
+    ups = T.ts_up_stream(int(ceil(nf * dflb / 188)), rng)
+    bb = T.bbframe_stream(kbch, nf, ups)
+    scr = T.oracle_bb_descramble(bb)  # the PRBS XOR is its own inverse: this is the scrambled BBFRAME
+    m, prim = T.BCH_FIELDS[capi.FECFRAME_SHORT]
+    ob = T.OracleBch(m, prim, fi["bch_t"], fi["bch_n"])
+    cw = ob.encode_bytes(scr)
+    n_err = [int(rng.integers(0, fi["bch_t"] + 1)) for _ in range(nf)]
+    n_err[20] = n_err[41] = 40  # beyond t
+    rx = np.stack([T.flip_bits(cw[i], rng.choice(ob.n, n_err[i], replace=False)) for i in range(nf)])
+    want_msg, want_ret = ob.decode_bytes(rx)
+    want_bb = T.oracle_bb_descramble(want_msg)
+    want_ts = T.OracleBbDeheader(kbch).work(want_bb)
+    assert (want_ret[[20, 41]] == -1).all() and np.array_equal(want_bb[0], bb[0])
+
+    dec = BchDecoder(framesize=capi.FECFRAME_SHORT, rate="C1_2", max_frames=nf)
+    dec.set_descramble(True)
+    dh = BbDeheader(framesize=capi.FECFRAME_SHORT, rate="C1_2", max_frames=nf)
+    st = torch.cuda.current_stream().cuda_stream
+    d_cw = torch.from_numpy(rx).cuda()
+    d_msg = torch.empty((nf, kbch // 8), dtype=torch.uint8, device="cuda")
+    d_corr = torch.empty(nf, dtype=torch.int32, device="cuda")
+    d_ts = torch.zeros(nf * dh.max_out_bytes_per_frame, dtype=torch.uint8, device="cuda")
+    dec.work_device(d_cw.data_ptr(), nf, d_msg.data_ptr(), d_corr.data_ptr(), st)
+    dh.work_device(d_msg.data_ptr(), nf, d_ts.data_ptr(), st)
+    n = dh.finish(st)
+    assert d_corr.cpu().numpy().tolist() == want_ret.tolist()
+    assert n == want_ts.size and np.array_equal(d_ts[:n].cpu().numpy(), want_ts)
+    # every packet of a cleanly decoded stretch is one of the packets that were sent
+    sent = {bytes(ups[i:i + 188]) for i in range(0, ups.size, 188)}
+    got = [bytes(want_ts[i:i + 188]) for i in range(0, want_ts.size, 188)]
+    assert sum(p in sent for p in got) >= len(got) - 8 and len(got) > 200
+    dec.close(); dh.close()
