@@ -10,7 +10,7 @@
 //               alpha^(i*e mod P) for each set bit of exponent e (== remainder-then-evaluate of the
 //               reference, lib/bch.cc:176-189,217-222: rem(alpha^i) = r(alpha^i), and rem == 0 <=> all S_i == 0);
 //               S_2i = S_i^2.
-//   sigma(x)    simplified Berlekamp table (lib/bch.cc:225-304), one thread, log/antilog arithmetic.
+//   sigma(x)    simplified Berlekamp table (lib/bch.cc:225-304), one wavefront (lane = coefficient column), log/antilog arithmetic.
 //   roots       degree 1 and 2 closed forms (lib/bch.cc:316-367); otherwise a Chien search over the
 //               exponents [s+1, n+s] (lib/bch.cc:376-384, lib/gf.cc:376-401), all threads, LDS gathers.
 //   correction  message bits only, network bit order (lib/bch.cc:429-452).
@@ -91,6 +91,22 @@ __device__ __forceinline__ uint32_t modP(uint32_t x, int m, uint32_t P)
     return x >= P ? x - P : x;
 }
 
+// xor / max over the 64 lanes of a wavefront, result in every lane: four DPP exchange stages inside the rows of 16 lanes, then the
+// four row results through v_readlane
+template <int CTRL> __device__ __forceinline__ int bch_dpp(int v) { return __builtin_amdgcn_mov_dpp(v, CTRL, 0xf, 0xf, true); }
+__device__ __forceinline__ uint32_t wave_xor(uint32_t x)
+{
+    int v = (int)x;
+    v ^= bch_dpp<0xB1>(v); v ^= bch_dpp<0x4E>(v); v ^= bch_dpp<0x141>(v); v ^= bch_dpp<0x140>(v); // quad xor 1, xor 2, half-row mirror, row mirror
+    return (uint32_t)(__builtin_amdgcn_readlane(v, 0) ^ __builtin_amdgcn_readlane(v, 16) ^ __builtin_amdgcn_readlane(v, 32) ^ __builtin_amdgcn_readlane(v, 48));
+}
+__device__ __forceinline__ int wave_max(int x)
+{
+    int v = x;
+    v = max(v, bch_dpp<0xB1>(v)); v = max(v, bch_dpp<0x4E>(v)); v = max(v, bch_dpp<0x141>(v)); v = max(v, bch_dpp<0x140>(v));
+    return max(max(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)), max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+
 __global__ __launch_bounds__(kBchThreads) void bch_decode_kernel(BchArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -160,46 +176,63 @@ __global__ __launch_bounds__(kBchThreads) void bch_decode_kernel(BchArgs a)
         }
         __syncthreads();
 
-        if (tid == 0) {
+        if (tid < 64) { // the first wavefront; lane c owns coefficient column c of the Berlekamp rows and the bookkeeping of row c
+            const int lane = tid;
             auto lg = [&](uint32_t x) -> uint32_t { return a.log[x]; };
             auto mul = [&](uint32_t x, uint32_t y) -> uint32_t { return (!x || !y) ? 0u : (uint32_t)al[modP(lg(x) + lg(y), m, P)]; };
             auto inv = [&](uint32_t x) -> uint32_t { return (uint32_t)al[modP(P - lg(x), m, P)]; }; // x != 0
-            bool any = false;
-            for (int u = 0; u < t; u++) any |= S[2 * u] != 0;
-            if (!any) { ctl[2] = 0; ctl[3] = 0; } // error-free fast path (lib/bch.cc:181-182,484-486)
+            const bool any = __ballot(lane < t && S[2 * (lane < t ? lane : 0)] != 0) != 0;
+            if (!any) { if (lane == 0) { ctl[2] = 0; ctl[3] = 0; } } // error-free fast path (lib/bch.cc:181-182,484-486)
             else {
-                // even syndromes: S_2i = S_i^2
-                for (int i = 2; i <= 2 * t; i += 2) S[i - 1] = mul(S[i / 2 - 1], S[i / 2 - 1]);
-                // ---- simplified Berlekamp (lib/bch.cc:225-304) ----
-                for (int r = 0; r < t + 3; r++) for (int c = 0; c < kSigW; c++) sg[r][c] = 0;
-                two_mu[0] = -1;
-                for (int i = 0; i < t + 1; i++) two_mu[i + 1] = 2 * i;
-                sg[0][0] = 1; dg[0] = 0; sg[1][0] = 1; dg[1] = 0;
-                sg[2][0] = 1; sg[2][1] = S[0]; dg[2] = S[0] ? 1 : 0;
-                d[0] = 1; d[1] = S[0];
+                // even syndromes S_2i = S_i^2: lane i squares S_i; S_i of an even i is itself a square of an earlier pass (chains
+                // 1 -> 2 -> 4 -> 8 -> 16 and 3 -> 6 -> 12 -> 24: four passes)
+                for (int pass = 0; pass < 4; pass++) {
+                    const uint32_t src = (lane >= 1 && lane <= t) ? S[lane - 1] : 0u;
+                    const uint32_t sq = mul(src, src);
+                    if (lane >= 1 && lane <= t) S[2 * lane - 1] = sq;
+                }
+                // ---- simplified Berlekamp (lib/bch.cc:225-304), one wavefront: the discrepancy is an xor over lanes, the choice of
+                // rho a max over lanes of (2 rho - degree, rho) -- the reference scans rho downwards and takes a strictly larger
+                // difference, i.e. the LARGEST rho among the best --, the row update one multiply per lane ----
+                for (int r = 0; r < t + 3; r++) if (lane < kSigW) sg[r][lane] = 0;
+                // per-lane bookkeeping of row `lane`: d, degree, 2 mu
+                uint32_t d_l = lane == 0 ? 1u : lane == 1 ? S[0] : 0u;
+                int dg_l = lane == 2 ? (S[0] ? 1 : 0) : 0;
+                const int two_mu_l = lane == 0 ? -1 : 2 * (lane - 1);
+                if (lane == 0) { sg[0][0] = 1; sg[1][0] = 1; sg[2][0] = 1; sg[2][1] = S[0]; }
+                int dg_row = S[0] ? 1 : 0; // degree of the current row (uniform)
                 int row = 2;
                 while (row <= t) {
-                    const int tm = two_mu[row];
-                    uint32_t dr = S[tm];
-                    for (int j = 1; j <= dg[row]; j++) if (sg[row][j]) dr ^= mul(sg[row][j], S[tm - j]);
-                    d[row] = dr;
-                    if (dr == 0) { for (int c = 0; c < kSigW; c++) sg[row + 1][c] = sg[row][c]; dg[row + 1] = dg[row]; }
+                    const int tm = 2 * (row - 1);
+                    const uint32_t mine = lane < kSigW ? sg[row][lane] : 0u;
+                    uint32_t term = 0;
+                    if (lane == 0) term = S[tm];
+                    else if (lane <= dg_row && mine) term = mul(mine, S[tm - lane]);
+                    const uint32_t dr = wave_xor(term);
+                    if (lane == row) d_l = dr;
+                    int dg_next;
+                    if (dr == 0) { if (lane < kSigW) sg[row + 1][lane] = mine; dg_next = dg_row; }
                     else {
-                        int row_rho = 0, max_diff = -2;
-                        for (int j = row - 1; j >= 0; j--)
-                            if (d[j] != 0) { const int diff = two_mu[j] - dg[j]; if (diff > max_diff) { max_diff = diff; row_rho = j; } }
-                        const int shift = tm - two_mu[row_rho];
-                        const uint32_t coef = mul(dr, inv(d[row_rho]));
-                        for (int c = 0; c < kSigW; c++) sg[row + 1][c] = sg[row][c];
-                        int top = dg[row];
-                        for (int j = 0; j <= dg[row_rho]; j++) sg[row + 1][j + shift] ^= mul(coef, sg[row_rho][j]); // j + shift <= 2t - 1
-                        if (dg[row_rho] + shift > top) top = dg[row_rho] + shift;
-                        while (top >= 0 && sg[row + 1][top] == 0) top--;
-                        dg[row + 1] = top;
+                        const int key = (lane < row && d_l != 0) ? (((two_mu_l - dg_l + 32) << 8) | lane) : -1;
+                        const int best = wave_max(key);
+                        const int row_rho = best & 0xff;
+                        const int shift = tm - (row_rho == 0 ? -1 : 2 * (row_rho - 1));
+                        const uint32_t d_rho = (uint32_t)__builtin_amdgcn_readlane((int)d_l, row_rho);
+                        const int dg_rho = __builtin_amdgcn_readlane(dg_l, row_rho);
+                        const uint32_t coef = mul(dr, inv(d_rho));
+                        uint32_t nv = mine;
+                        const int src = lane - shift;
+                        if (lane < kSigW && src >= 0 && src <= dg_rho) nv ^= mul(coef, sg[row_rho][src]); // src + shift <= 2t - 1
+                        if (lane < kSigW) sg[row + 1][lane] = nv;
+                        const unsigned long long nz = __ballot(lane < kSigW && nv != 0);
+                        dg_next = nz ? 63 - __clzll((long long)nz) : -1;
                     }
+                    if (lane == row + 1) dg_l = dg_next;
+                    dg_row = dg_next;
                     row++;
                 }
-                const int deg = dg[row];
+                if (lane == 0) {
+                const int deg = dg_row;
                 const uint32_t* sigma = sg[row];
                 ctl[0] = deg;
                 // ---- error-location numbers (lib/bch.cc:307-385) ----
@@ -227,6 +260,7 @@ __global__ __launch_bounds__(kBchThreads) void bch_decode_kernel(BchArgs a)
                 }
                 ctl[2] = mode; ctl[3] = status;
                 if (mode == 1 && status == -2) ctl[2] = 3; // nothing to apply
+                }
             }
         }
         __syncthreads();
@@ -236,11 +270,25 @@ __global__ __launch_bounds__(kBchThreads) void bch_decode_kernel(BchArgs a)
         if (mode == 2) {
             // ---- Chien search over exponents [s+1, n+s]; a degree-deg polynomial has at most deg roots, so
             // collecting all of them equals the reference's early-stopping scan ----
-            for (uint32_t i = (uint32_t)a.s + 1 + tid; i <= (uint32_t)(n + a.s); i += kBchThreads) {
+            // sigma(alpha^i) = xor_j alpha^(log sigma_j + i j): a thread walks i = i0, i0 + 1024, ... and keeps the exponent of every
+            // term, advanced by (1024 j mod P) per step (an add and a conditional subtract instead of a multiply and a reduction)
+            uint32_t ex[kMaxT + 1], st[kMaxT + 1];
+            const uint32_t i0 = (uint32_t)a.s + 1 + tid;
+#pragma unroll
+            for (int j = 0; j <= kMaxT; j++) {
+                const uint32_t l = j <= deg ? lsig[j] : 0xffffffffu;
+                st[j] = modP((uint32_t)kBchThreads * (uint32_t)j, m, P);
+                ex[j] = l == 0xffffffffu ? 0xffffffffu : modP(l + modP(i0 * (uint32_t)j, m, P), m, P);
+            }
+            for (uint32_t i = i0; i <= (uint32_t)(n + a.s); i += kBchThreads) {
                 uint32_t res = 0;
-                for (int j = 0; j <= deg; j++) {
-                    const uint32_t l = lsig[j];
-                    if (l != 0xffffffffu) res ^= al[modP(l + i * (uint32_t)j, m, P)];
+#pragma unroll
+                for (int j = 0; j <= kMaxT; j++) {
+                    if (ex[j] != 0xffffffffu) {
+                        res ^= al[ex[j]];
+                        uint32_t e = ex[j] + st[j];
+                        ex[j] = e >= P ? e - P : e;
+                    }
                 }
                 if (res == 0) { const int idx = atomicAdd(&ctl[1], 1); if (idx < 16) roots[idx] = i; }
             }
