@@ -159,7 +159,7 @@ LdpcDecoderHip::LdpcDecoderHip(const LdpcTableDesc* table, int out_bits_message,
         // Two-level walk (check_node_hazard): ONE pair of hazard entries is closer than every other pair by a factor of two or more.
         // It goes first (entries 0, 1); word 2 of the record = the distance of the nearest OTHER pair = rows per outer block.
         uint32_t block2 = 0;
-        if (hz2_ && two_level_on && L.block < 360 && nc_code >= 4 && nc_code != (uint32_t)kHazardWalk) {
+        if (hz2_ && two_level_on && L.block < 360 && nc_code >= 4 && nc_code != (uint32_t)kHazardWalk && (L.cnt + 2 < 29 || nc_code == 8)) {
             int best_a = -1, best_b = -1, d1 = 360, d2 = 360;
             for (int a = 0; a < L.n_conflict; a++)
                 for (int b = a + 1; b < L.n_conflict; b++) {

@@ -680,8 +680,11 @@ __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, con
     // ordered steps of B rows -- a two-entry step instead of an NC-entry one -- and at the end of the outer block its rows write the
     // far entries back. 360 / B short steps + 360 / block2 long ones instead of 360 / B long ones (B11 layer 5: B = 4).
     bool two_level = false;
-    if constexpr (NC >= 4 && TWO) two_level = block2 > 0;
-    if constexpr (NC >= 4 && TWO) if (two_level) {
+    // (degree 29 and above: only the eight-entry form is compiled -- every instantiation costs that class registers, and 9/10 normal,
+    // the table it is there for, has its block-4 layer with eight ordered entries)
+    constexpr bool kTwoBuilt = TWO && NC >= 4 && (DEG < 29 || NC == 8);
+    if constexpr (kTwoBuilt) two_level = block2 > 0;
+    if constexpr (kTwoBuilt) if (two_level) {
         for (int sb = 0; sb < kM; sb += block2) {
             const bool in_sb = work && (uint32_t)(jj - sb) < (uint32_t)block2;
             int minF = min0, signsF = signs;
