@@ -353,3 +353,32 @@ def test_rows_whose_bch_length_is_not_the_table_k(framesize, rate):
     assert ret.tolist() == wret and np.array_equal(out, want)
     assert np.array_equal(bits, T.pack_bits(want, fi["ldpc_k"]))
     dec.close()
+
+
+def test_enqueue_finish_contract():
+    """One call may be outstanding per handle: a second enqueue before finish() is refused (and does not disturb the first), finish()
+    without a call is a no-op, a failed call does not poison the handle, results of the first call are complete after its finish()."""
+    import torch
+    from dvbs2rx_amd.capi import Dvbs2Error
+    table = "S2_TABLE_C1"
+    N, K, _, _ = T.ldpc_info(table)
+    nf, G, cap = 64, 32, 25
+    llr, _ = T.llr_codeword_awgn(table, nf, 5, amp=5, sigma=6.0)
+    want, wret = checker(table, llr, G, cap)
+    st = torch.cuda.current_stream().cuda_stream
+    dec = LdpcDecoder(table=table, message_bits=K, group_size=G, max_frames=nf, max_trials=cap, outputmode=capi.OM_MESSAGE)
+    dec.finish()  # nothing outstanding
+    d_in = torch.from_numpy(llr).cuda()
+    d_bits = torch.zeros((nf, K // 8), dtype=torch.uint8, device="cuda")
+    d_ret = torch.zeros(nf // G, dtype=torch.int32, device="cuda")
+    dec.enqueue_device(d_in.data_ptr(), nf, d_bits.data_ptr(), 0, d_ret.data_ptr(), st)
+    with pytest.raises(Dvbs2Error):
+        dec.enqueue_device(d_in.data_ptr(), nf, d_bits.data_ptr(), 0, d_ret.data_ptr(), st)
+    dec.finish()
+    assert d_ret.cpu().tolist() == wret and np.array_equal(d_bits.cpu().numpy(), T.pack_bits(want, K))
+    with pytest.raises(Dvbs2Error):  # more frames than the handle was made for
+        dec.work_device(d_in.data_ptr(), nf + 32, d_bits.data_ptr(), 0, d_ret.data_ptr(), st)
+    d_bits.zero_()
+    dec.work_device(d_in.data_ptr(), nf, d_bits.data_ptr(), 0, d_ret.data_ptr(), st)  # the handle still works
+    assert np.array_equal(d_bits.cpu().numpy(), T.pack_bits(want, K))
+    dec.close()
