@@ -14,10 +14,18 @@ under "configs" (each with its own parity gate, timing and roofline object):
   config4  QPSK 1/4 short (S2_TABLE_C1), 25 iterations, 16384 frames
   config5  9/10 normal from LLRs: LDPC (S2_TABLE_B11) + BCH(58320,58192,8), 4096 frames per GPU (32768 over 8 GPUs)
   config5_s2x  S2X 154/180 normal from LLRs: LDPC (S2X_TABLE_B21) + BCH(55440,55248,12), 4096 frames per GPU
-config 1 (one frame through a CPU path) has no counterpart: the library has no CPU path by design.
+and the SURVEY 8(d) secondaries of config 2:
+  config2_awgn  the operating point: valid codewords, QPSK + AWGN, LLR = clamp(rint(2 sqrt(2) y / N0)) (the demapper's map), groups
+                stop at different counts; mean updates and the roofline on the updates actually executed
+  config2_host  the host-buffer entry dvbs2_ldpc_decode (H2D / D2H inclusive; pageable and page-locked caller buffers)
+plus `device_copy` (measured device-to-device copy bandwidth beside the 8 TB/s nominal peak).
+Every parity gate compares the WHOLE batch with the genuine reference run on all host cores (--gate first: first group only).
+config 1 (one frame through a CPU path) has no counterpart in the bench: the library has no CPU path by design; its
+workload runs on the HIP path in tests/test_ldpc_gpu.py::test_baseline_config1_one_frame_replicated.
 Prints ONE JSON line (rank 0).
 """
 import argparse
+import hashlib
 import json
 import os
 import subprocess
@@ -96,12 +104,26 @@ def cpu_baseline(table, N, trials, one_core_s=3.0, all_core_s=6.0):
             "logical_cpus": len(os.sched_getaffinity(0))}
 
 
+def csrc_sha256():
+    """Digest of the kernel sources (every file of gr-dvbs2rx_amd/csrc, names and contents): profiles/traffic.json records the
+    tree it was profiled at (tools/gen_traffic.py) and is only believed for exactly that tree."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "gr-dvbs2rx_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        h.update(name.encode() + b"\0")
+        h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()
+
+
 def measured_traffic(config, kernel, frames, trials):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/traffic.json <-
-    tools/gen_traffic.py), when the profiled configuration (name, kernel build, batch, cap) equals the one being run; None otherwise."""
+    tools/gen_traffic.py), when the profiled configuration (name, kernel build, batch, cap) equals the one being run AND the
+    kernel sources are the ones that were profiled (csrc_sha256); None otherwise."""
     try:
         t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
     except Exception:
+        return None
+    if t.get("csrc_sha256") != csrc_sha256():
         return None
     for e in t.get("entries", []):
         if e.get("config") == config and e["kernel"] == kernel and e["frames_per_launch"] == frames and e["max_trials"] == trials:
@@ -114,10 +136,13 @@ def timed(step, steps, warmup, shard, dev):
     """W untimed steps, then exactly K steps between barrier + synchronize on both sides; max over ranks."""
     for _ in range(warmup):
         step()
+    import torch
     shard.barrier_sync()
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
+    torch.cuda.synchronize()
+    timed.own_s = time.perf_counter() - t0  # this rank alone, before it waits for the others (per-rank report at N > 1)
     shard.barrier_sync()
     return shard.max_over_ranks(time.perf_counter() - t0, device=dev)
 
@@ -140,44 +165,52 @@ def noise_llr(torch, nf, N, dev, seed):
     return torch.clamp(torch.round(torch.randn((nf, N), generator=g, device=dev) * 8.0), -128, 127).to(torch.int8)
 
 
-def ldpc_gate(T, np, torch, dec, table, llr, G, trials, stream):
-    """GPU output of the first group must equal the CPU checker bit for bit (genuine reference when present)."""
-    N = llr.shape[1]
-    d_out = torch.empty((G, N), dtype=torch.int8, device=llr.device)
-    d_b = torch.empty((G, dec.out_bytes), dtype=torch.uint8, device=llr.device)
-    d_r = torch.empty(1, dtype=torch.int32, device=llr.device)
-    dec.work_device(llr.data_ptr(), G, d_b.data_ptr(), d_out.data_ptr(), d_r.data_ptr(), stream)
-    x = llr[:G].cpu().numpy()
+def ldpc_gate(T, np, torch, dec, table, llr, G, trials, stream, full=True):
+    """GPU output must equal the CPU checker bit for bit: the WHOLE batch against the genuine AVX2 reference on all host cores
+    (full), or the first group only."""
+    nf, N = (llr.shape[0] if full and T.ref_ldpc() is not None and G == 32 else G), llr.shape[1]
+    d_out = torch.empty((nf, N), dtype=torch.int8, device=llr.device)
+    d_b = torch.empty((nf, dec.out_bytes), dtype=torch.uint8, device=llr.device)
+    d_r = torch.empty((nf + G - 1) // G, dtype=torch.int32, device=llr.device)
+    dec.work_device(llr.data_ptr(), nf, d_b.data_ptr(), d_out.data_ptr(), d_r.data_ptr(), stream)
+    x = llr[:nf].cpu().numpy()
     if T.ref_ldpc() is not None and G in (16, 32):
-        want, wret = T.ref_ldpc_decode(table, x, 0 if G == 32 else 2, trials); who = "reference AVX2" if G == 32 else "reference generic"
+        want, wret = T.ref_ldpc_decode_parallel(table, x, 0 if G == 32 else 2, trials); who = "reference AVX2" if G == 32 else "reference generic"
     else:
         want, wret = T.oracle_ldpc_decode(table, x, G, trials); who = "oracle"
     ok = (d_r.cpu().tolist() == wret and np.array_equal(d_out.cpu().numpy(), want)
           and np.array_equal(d_b.cpu().numpy(), T.pack_bits(want, dec.message_bits)))
     if not ok:
         raise RuntimeError(f"PARITY FAILURE ({table}): GPU decode differs from the CPU checker; no number reported")
-    return "bit-exact vs " + who
+    return f"bit-exact vs {who}, {nf} of {llr.shape[0]} frames (LLRs, bits, return values)", wret
 
 
-def chain_gate(T, np, torch, chain, fi, llr, G, trials, stream, fs):
-    """LLR-domain chain: first group vs genuine LDPC reference + BCH restatement (pinned by the reference's digests)."""
-    nfr = G
-    d_msg = torch.empty((nfr, chain.msg_bytes), dtype=torch.uint8, device=llr.device)
-    d_r = torch.empty(1, dtype=torch.int32, device=llr.device)
-    d_c = torch.empty(nfr, dtype=torch.int32, device=llr.device)
-    chain.work_llr_device(llr.data_ptr(), nfr, d_msg.data_ptr(), d_r.data_ptr(), d_c.data_ptr(), stream)
-    x = llr[:nfr].cpu().numpy()
-    if T.ref_ldpc() is not None and G == 32:
-        dec_llr, wret = T.ref_ldpc_decode(fi["table"], x, 0, trials); who = "reference AVX2 LDPC"
-    else:
-        dec_llr, wret = T.oracle_ldpc_decode(fi["table"], x, G, trials); who = "oracle LDPC"
-    m, prim = T.BCH_FIELDS[fs]
-    want_msg, want_corr = T.OracleBch(m, prim, fi["bch_t"], fi["bch_n"]).decode_bytes(T.pack_bits(dec_llr, fi["bch_n"]))
-    ok = (d_r.cpu().tolist() == wret and d_c.cpu().numpy().tolist() == want_corr.tolist()
-          and np.array_equal(d_msg.cpu().numpy(), want_msg))
+def chain_check(T, np, fi, llr_host, trials, fs, msg, ret, corr, what):
+    """Chain outputs (messages, LDPC return values, BCH results) of the frames in llr_host vs the CPU chain."""
+    want_msg, want_corr, wret, who = T.chain_expect(fi["table"], fi["bch_n"], fi["bch_t"], fs, llr_host, trials)
+    nfr = llr_host.shape[0]
+    ok = (ret[:len(wret)].cpu().tolist() == wret and corr[:nfr].cpu().numpy().tolist() == want_corr.tolist()
+          and np.array_equal(msg[:nfr].cpu().numpy(), want_msg))
     if not ok:
         raise RuntimeError(f"PARITY FAILURE (chain {fi['table']}): GPU chain differs from the CPU checker")
-    return f"bit-exact vs {who} + BCH oracle"
+    return f"bit-exact vs {what}{who}, {nfr} frames (messages, BCH results, LDPC return values)"
+
+
+def device_copy_bandwidth(torch, dev):
+    """Measured device-to-device copy rate (read + write bytes per second): the practical HBM ceiling beside the nominal peak."""
+    n = 1 << 30
+    a = torch.empty(n, dtype=torch.uint8, device=dev); b = torch.empty_like(a)
+    a.fill_(1)
+    for _ in range(2):
+        b.copy_(a)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        b.copy_(a)
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 10
+    return {"bytes_copied": n, "ms": ms, "read_plus_write_gbs": 2 * n / ms / 1e6, "nominal_peak_gbs": HBM_PEAK_GBS,
+            "frac_of_nominal": 2 * n / ms / 1e6 / HBM_PEAK_GBS}
 
 
 def main():
@@ -192,6 +225,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="headline only (profiling runs)")
     ap.add_argument("--only", default="", help="comma list of extra configs to run (default: all at N=1, config5 at N>1)")
+    ap.add_argument("--gate", choices=["full", "first", "none"], default="full",
+                    help="parity gates: whole batch vs the genuine reference on all host cores / first group / none (profiling passes)")
+    ap.add_argument("--esn0", type=float, default=2.0, help="Es/N0 in dB of the operating-point run (config2_awgn)")
     args = ap.parse_args()
 
     import numpy as np
@@ -214,17 +250,27 @@ def main():
     info = ldpc_table_info(table)
     N, K = info["N"], info["K"]
     nf = args.frames
+    gate_on, gate_full = args.gate != "none", args.gate == "full"
     dec = LdpcDecoder(standard=capi.STANDARD_DVBS2, framesize=capi.FECFRAME_NORMAL, rate="C1_2",
                       outputmode=capi.OM_MESSAGE, max_trials=args.trials, group_size=G, max_frames=nf, device=local)
     out_bytes = dec.out_bytes
-    if args.input == "noise":
-        llr = noise_llr(torch, nf, N, dev, 12345 + rank)
-    else:
-        base, _ = T.llr_codeword_awgn(table, 64, 4242 + rank, amp=6, sigma=5.2)
-        llr = torch.from_numpy(np.tile(base, (nf // 64 + 1, 1))[:nf]).to(dev)
+
+    def awgn_llr(seed):
+        """SURVEY 8(d) secondary input: valid codewords (64 distinct, CPU encoder of the test library), QPSK symbols
+        (1 - 2c) / sqrt(2) per dimension + AWGN of variance N0 / 2, fresh noise for every frame, through the demapper's map
+        LLR = clamp(rint(2 sqrt(2) y / N0)) (lib/qpsk.h:208-214)."""
+        rng = np.random.default_rng(seed)
+        cw = T.ldpc_encode(table, rng.integers(0, 2, (64, K), dtype=np.uint8))
+        n0 = 10.0 ** (-args.esn0 / 10.0)
+        tx = torch.from_numpy(np.tile((1.0 - 2.0 * cw.astype(np.float32)) * np.float32(0.5 ** 0.5), (nf // 64 + 1, 1))[:nf]).to(dev)
+        g = torch.Generator(device=dev); g.manual_seed(seed)
+        y = tx + (n0 / 2.0) ** 0.5 * torch.randn((nf, N), generator=g, device=dev)
+        return torch.clamp(torch.round(y * (2.0 * 2.0 ** 0.5 / n0)), -128, 127).to(torch.int8)
+
+    llr = noise_llr(torch, nf, N, dev, 12345 + rank) if args.input == "noise" else awgn_llr(4242 + rank)
     d_bits = torch.empty((nf, out_bytes), dtype=torch.uint8, device=dev)
     d_ret = torch.empty((nf + G - 1) // G, dtype=torch.int32, device=dev)
-    parity = ldpc_gate(T, np, torch, dec, table, llr, G, args.trials, stream) if rank == 0 else "skipped"
+    parity = ldpc_gate(T, np, torch, dec, table, llr, G, args.trials, stream, gate_full)[0] if rank == 0 and gate_on else "skipped"
 
     def step():
         dec.work_device(llr.data_ptr(), nf, d_bits.data_ptr(), 0, d_ret.data_ptr(), stream)
@@ -233,8 +279,9 @@ def main():
         step()
     dec.profile(True)  # HIP events around the dominant kernel, on its launch stream
     dt = timed(step, args.steps, 0, shard, dev)
-    iters_mean = float((args.trials - d_ret.clamp(min=0)).float().mean().item()) if args.input != "noise" else float(args.trials)
-    b_alg = ldpc_bytes(N, out_bytes, info["links_total"], args.trials if args.input == "noise" else iters_mean)
+    own_s = timed.own_s
+    iters_mean = float(torch.where(d_ret < 0, torch.full_like(d_ret, args.trials), args.trials - d_ret).float().mean().item())
+    b_alg = ldpc_bytes(N, out_bytes, info["links_total"], iters_mean)
     rl = roofline(dec, b_alg, nf, measured_traffic("config2", dec.kernel_name, nf, args.trials) if args.input == "noise" else None)
     rl["limiter"] = "VALU pipe (half-rate min/med3/sad/add3), not HBM: DESIGN.md 3.3"
     fps = world * nf * args.steps / dt
@@ -250,6 +297,14 @@ def main():
                    "mean_iterations": iters_mean, "parallelism": f"frames sharded over {world} GPU(s), no collective"},
         "parity": parity, "roofline": rl,
     }
+    if world > 1:
+        # every rank's own rate over the same K steps (its clock from the common start to ITS last step's completion): the spread
+        # shows whether the ranks run evenly or one is held back (host feed, a slower device)
+        per_rank = shard.gather_over_ranks(nf * args.steps / own_s, device=dev)
+        out["per_rank"] = {"frames_per_s": per_rank, "min": min(per_rank), "max": max(per_rank),
+                           "spread": (max(per_rank) - min(per_rank)) / max(per_rank),
+                           "note": "each rank's own clock over the same K steps (common start after the barrier, its own last "
+                                   "completion); `value` uses the slowest rank's time"}
     dec.close()
     del llr, d_bits
 
@@ -265,7 +320,7 @@ def main():
         x = noise_llr(torch, frames, ti["N"], dev, 777 + rank)
         b = torch.empty((frames, d.out_bytes), dtype=torch.uint8, device=dev)
         r = torch.empty((frames + G - 1) // G, dtype=torch.int32, device=dev)
-        par = ldpc_gate(T, np, torch, d, tbl, x, G, trials, stream) if rank == 0 else "skipped"
+        par = ldpc_gate(T, np, torch, d, tbl, x, G, trials, stream, gate_full)[0] if rank == 0 and gate_on else "skipped"
         fn = lambda: d.work_device(x.data_ptr(), frames, b.data_ptr(), 0, r.data_ptr(), stream)
         fn(); d.profile(True)
         t = timed(fn, steps2, 0, shard, dev)
@@ -283,9 +338,13 @@ def main():
         m = torch.empty((frames, ch.msg_bytes), dtype=torch.uint8, device=dev)
         r = torch.empty((frames + G - 1) // G, dtype=torch.int32, device=dev)
         c = torch.empty(frames, dtype=torch.int32, device=dev)
-        par = chain_gate(T, np, torch, ch, fi, x, G, trials, stream, capi.FECFRAME_NORMAL) if rank == 0 else "skipped"
         fn = lambda: ch.work_llr_device(x.data_ptr(), frames, m.data_ptr(), r.data_ptr(), c.data_ptr(), stream)
-        fn(); ch.profile(True)
+        fn()
+        par = "skipped"
+        if rank == 0 and gate_on:
+            ng = frames if gate_full and T.ref_ldpc() is not None and G == 32 else G
+            par = chain_check(T, np, fi, x[:ng].cpu().numpy(), trials, capi.FECFRAME_NORMAL, m, r, c, "")
+        ch.profile(True)
         t = timed(fn, steps2, 0, shard, dev)
         bl = ldpc_bytes(ti["N"], fi["bch_n"] // 8, ti["links_total"], trials)
         b_step = bl + fi["bch_n"] // 8 + fi["bch_k"] // 8
@@ -307,19 +366,13 @@ def main():
             r = torch.empty((nf + G - 1) // G, dtype=torch.int32, device=dev)
             c = torch.empty(nf, dtype=torch.int32, device=dev)
             fn = lambda: ch.work_device(syms.data_ptr(), nf, n0.data_ptr(), 1, msg.data_ptr(), r.data_ptr(), c.data_ptr(), stream)
+            fn()
             par = "skipped"
-            if rank == 0:  # first group through the CPU checkers: demapper restatement -> genuine LDPC -> BCH restatement
-                fn()
-                rx = syms[:G].cpu().numpy().view(np.complex64)
-                x = T.oracle_demap(rx, np.float32(1.0), 8, 0)
-                dl, wret = (T.ref_ldpc_decode(fi["table"], x, 0, args.trials) if T.ref_ldpc() is not None and G == 32
-                            else T.oracle_ldpc_decode(fi["table"], x, G, args.trials))
-                m_, prim = T.BCH_FIELDS[capi.FECFRAME_NORMAL]
-                wm, wc = T.OracleBch(m_, prim, fi["bch_t"], fi["bch_n"]).decode_bytes(T.pack_bits(dl, fi["bch_n"]))
-                if not (r[:1].cpu().tolist() == wret and c[:G].cpu().numpy().tolist() == wc.tolist() and np.array_equal(msg[:G].cpu().numpy(), wm)):
-                    raise RuntimeError("PARITY FAILURE (config3 chain)")
-                par = "bit-exact vs demapper oracle (parity unpinned) + reference AVX2 LDPC + BCH oracle"
-            fn(); ch.profile(True)
+            if rank == 0 and gate_on:  # the CPU chain: demapper restatement -> genuine LDPC on all cores -> BCH codec
+                ng = nf if gate_full and T.ref_ldpc() is not None and G == 32 else G
+                x = T.oracle_demap(syms[:ng].cpu().numpy().view(np.complex64), np.float32(1.0), 8, 0)
+                par = chain_check(T, np, fi, x, args.trials, capi.FECFRAME_NORMAL, msg, r, c, "demapper oracle (parity unpinned) + ")
+            ch.profile(True)
             t = timed(fn, steps2, 0, shard, dev)
             ti = ldpc_table_info(fi["table"])
             bl = ldpc_bytes(64800, fi["bch_n"] // 8, ti["links_total"], args.trials)
@@ -341,6 +394,81 @@ def main():
         if "config5_s2x" in want:
             llr_chain("config5_s2x", "C154_180", nf, args.trials,
                       f"S2X 154/180 normal from LLRs: LDPC (S2X_TABLE_B21) + BCH(55440,55248,12), {args.trials} iterations cap, {nf} frames per GPU, noise LLRs")
+        out["configs"] = configs
+
+    # ---------------------------------------------------------------- SURVEY 8(d) secondaries of config 2 (one GPU)
+    if world == 1 and not args.no_configs and args.input == "noise":
+        extras = [c for c in args.only.split(",") if c] or ["config2_awgn", "config2_host", "device_copy"]
+        bl50 = ldpc_bytes(N, out_bytes, info["links_total"], args.trials)
+        if "config2_awgn" in extras:
+            d = LdpcDecoder(standard=capi.STANDARD_DVBS2, framesize=capi.FECFRAME_NORMAL, rate="C1_2", outputmode=capi.OM_MESSAGE,
+                            max_trials=args.trials, group_size=G, max_frames=nf, device=local)
+            x = awgn_llr(4242)
+            b = torch.empty((nf, out_bytes), dtype=torch.uint8, device=dev)
+            r = torch.empty((nf + G - 1) // G, dtype=torch.int32, device=dev)
+            par = ldpc_gate(T, np, torch, d, table, x, G, args.trials, stream, gate_full)[0] if gate_on else "skipped"
+            fn = lambda: d.work_device(x.data_ptr(), nf, b.data_ptr(), 0, r.data_ptr(), stream)
+            fn(); d.profile(True)
+            t = timed(fn, steps2, 0, shard, dev)
+            upd = torch.where(r < 0, torch.full_like(r, args.trials), args.trials - r).float()
+            mean_upd = float(upd.mean().item())
+            bl = ldpc_bytes(N, out_bytes, info["links_total"], mean_upd)
+            val = nf * steps2 / t
+            rla = roofline(d, bl, nf)
+            configs["config2_awgn"] = {
+                "workload": f"QPSK 1/2 normal at the operating point: valid codewords, QPSK + AWGN at Es/N0 = {args.esn0} dB, LLR = "
+                            f"clamp(rint(2 sqrt(2) y / N0)), cap {args.trials}, batch={nf}, G={G} (at 1.5 dB the genuine reference does "
+                            "not converge within 50 updates with this LLR scale: DESIGN.md 7)",
+                "value": val, "unit": "frames/s", "coded_gbps": val * N / 1e9, "frames_per_gpu": nf, "max_trials": args.trials,
+                "steps": steps2, "ms_per_step": t / steps2 * 1e3, "parity": par, "es_n0_db": args.esn0,
+                "mean_updates_per_group": mean_upd, "min_updates": float(upd.min().item()), "max_updates": float(upd.max().item()),
+                "failed_groups": int((r < 0).sum().item()), "roofline": rla,
+                # the whole step (first pass + group resolution + finalize) against the bytes of the updates that ran, and against
+                # the never-converging rate scaled by cap / mean updates
+                "step_frac_of_hbm_peak": bl * val / 1e9 / HBM_PEAK_GBS,
+                "frac_of_proportional_rate": val / (out["value"] * args.trials / max(mean_upd, 1e-9))}
+            d.close(); del x
+        if "config2_host" in extras:
+            d = LdpcDecoder(standard=capi.STANDARD_DVBS2, framesize=capi.FECFRAME_NORMAL, rate="C1_2", outputmode=capi.OM_MESSAGE,
+                            max_trials=args.trials, group_size=G, max_frames=nf, device=local)
+            host = {}
+            for frames in (nf, 512):
+                xh = noise_llr(torch, frames, N, dev, 12345).cpu().numpy()
+                for mode in ("pageable", "registered"):
+                    bits_h = np.empty((frames, out_bytes), np.uint8); ret_h = np.empty((frames + G - 1) // G, np.int32)
+                    if mode == "registered":  # the caller page-locked its buffers once (dvbs2_host_register)
+                        for a in (xh, bits_h, ret_h):
+                            capi.check(capi.lib.dvbs2_host_register(a.ctypes.data, a.nbytes))
+                    call = lambda: capi.check(capi.lib.dvbs2_ldpc_decode(d._h, xh.ctypes.data, frames, args.trials, capi.OM_MESSAGE,
+                                                                         bits_h.ctypes.data, None, ret_h.ctypes.data))
+                    call()
+                    t0 = time.perf_counter()
+                    for _ in range(steps2):
+                        call()
+                    th = (time.perf_counter() - t0) / steps2
+                    dx = torch.from_numpy(xh).to(dev); db = torch.empty((frames, out_bytes), dtype=torch.uint8, device=dev)
+                    fnr = lambda: d.work_device(dx.data_ptr(), frames, db.data_ptr(), 0, 0, stream)
+                    fnr(); torch.cuda.synchronize(); t0 = time.perf_counter()
+                    for _ in range(steps2):
+                        fnr()
+                    torch.cuda.synchronize(); tr = (time.perf_counter() - t0) / steps2
+                    if not np.array_equal(bits_h, db.cpu().numpy()):
+                        raise RuntimeError("PARITY FAILURE: host-buffer entry differs from the device entry")
+                    host[f"{frames}_{mode}"] = {"frames_per_call": frames, "frames_per_s": frames / th, "ms_per_call": th * 1e3,
+                                                "resident_frames_per_s": frames / tr, "frac_of_resident": tr / th,
+                                                "pcie_in_gbs": frames * N / th / 1e9}
+                    if mode == "registered":
+                        for a in (xh, bits_h, ret_h):
+                            capi.check(capi.lib.dvbs2_host_unregister(a.ctypes.data))
+                    del dx, db
+            configs["config2_host"] = {"workload": "dvbs2_ldpc_decode (host buffers in and out: H2D + decode + D2H per synchronous call), "
+                                                   f"table B4, cap {args.trials}, noise LLRs; never the headline value", "unit": "frames/s",
+                                       "value": host[f"{nf}_pageable"]["frames_per_s"], "calls": host,
+                                       "step_frac_of_hbm_peak": bl50 * host[f"{nf}_pageable"]["frames_per_s"] / 1e9 / HBM_PEAK_GBS}
+            d.close()
+        if "device_copy" in extras:
+            out["device_copy"] = device_copy_bandwidth(torch, dev)
+            out["roofline"]["frac_of_measured_copy"] = out["roofline"]["achieved"] / out["device_copy"]["read_plus_write_gbs"]
         out["configs"] = configs
 
     if rank == 0:

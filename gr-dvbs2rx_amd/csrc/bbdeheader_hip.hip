@@ -183,6 +183,7 @@ int BbDeheaderHip::state(BbdhState* out, hipStream_t stream)
     if (!ok()) return -1;
     call_err_.clear();
     DeviceGuard guard(device_);
+    if (!guard.ok) { call_err_ = "hipSetDevice failed"; return -1; }
     hipError_t e = hipMemcpyAsync(out, d_state_, sizeof(BbdhState), hipMemcpyDeviceToHost, stream);
     if (e == hipSuccess) e = hipStreamSynchronize(stream);
     if (e != hipSuccess) { call_err_ = std::string("bbdeheader state: ") + hipGetErrorString(e); return -1; }
@@ -194,6 +195,7 @@ int BbDeheaderHip::reset(hipStream_t stream)
     if (!ok()) return -1;
     call_err_.clear();
     DeviceGuard guard(device_);
+    if (!guard.ok) { call_err_ = "hipSetDevice failed"; return -1; }
     hipError_t e = hipMemsetAsync(d_state_, 0, sizeof(BbdhState), stream);
     if (e != hipSuccess) { call_err_ = std::string("bbdeheader reset: ") + hipGetErrorString(e); return -1; }
     return 0;

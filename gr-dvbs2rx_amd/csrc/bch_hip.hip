@@ -124,9 +124,7 @@ __global__ __launch_bounds__(kBchThreads) void bch_decode_kernel(BchArgs a)
     // last row can reach 2t - 1 > t; the reference keeps every coefficient (gf2m_poly, lib/bch.cc:286-297) and "degree > t"
     // (lib/bch.cc:313-314) must be decided on the true degree
     constexpr int kSigW = 2 * kMaxT + 4;
-    int* dg = reinterpret_cast<int*>(w + 104);
-    uint32_t* d = w + 120;
-    int* two_mu = reinterpret_cast<int*>(w + 136);
+    // (w + 104 .. w + 159: the per-row bookkeeping of the one-thread Berlekamp of round 1; it lives in registers of lane `row` now)
     uint32_t (*sg)[kSigW] = reinterpret_cast<uint32_t (*)[kSigW]>(w + 160); // [kMaxT + 3][kSigW] = 420 dwords
     uint8_t* cwl = reinterpret_cast<uint8_t*>(w + kBchWorkWords);       // codeword bytes
 
@@ -178,6 +176,14 @@ __global__ __launch_bounds__(kBchThreads) void bch_decode_kernel(BchArgs a)
 
         if (tid < 64) { // the first wavefront; lane c owns coefficient column c of the Berlekamp rows and the bookkeeping of row c
             const int lane = tid;
+            // Lanes exchange S[] and sg[][] through LDS without a workgroup barrier (one wavefront, LDS operations of a wave
+            // execute in program order): the compiler must not move a lane's load across another lane's earlier store, so every
+            // hand-over point is a wavefront-scope release / barrier / acquire (no instruction is emitted for the barrier itself).
+            auto wave_lds_sync = [] {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            };
             auto lg = [&](uint32_t x) -> uint32_t { return a.log[x]; };
             auto mul = [&](uint32_t x, uint32_t y) -> uint32_t { return (!x || !y) ? 0u : (uint32_t)al[modP(lg(x) + lg(y), m, P)]; };
             auto inv = [&](uint32_t x) -> uint32_t { return (uint32_t)al[modP(P - lg(x), m, P)]; }; // x != 0
@@ -190,6 +196,7 @@ __global__ __launch_bounds__(kBchThreads) void bch_decode_kernel(BchArgs a)
                     const uint32_t src = (lane >= 1 && lane <= t) ? S[lane - 1] : 0u;
                     const uint32_t sq = mul(src, src);
                     if (lane >= 1 && lane <= t) S[2 * lane - 1] = sq;
+                    wave_lds_sync(); // the next pass squares what other lanes wrote in this one
                 }
                 // ---- simplified Berlekamp (lib/bch.cc:225-304), one wavefront: the discrepancy is an xor over lanes, the choice of
                 // rho a max over lanes of (2 rho - degree, rho) -- the reference scans rho downwards and takes a strictly larger
@@ -199,7 +206,9 @@ __global__ __launch_bounds__(kBchThreads) void bch_decode_kernel(BchArgs a)
                 uint32_t d_l = lane == 0 ? 1u : lane == 1 ? S[0] : 0u;
                 int dg_l = lane == 2 ? (S[0] ? 1 : 0) : 0;
                 const int two_mu_l = lane == 0 ? -1 : 2 * (lane - 1);
+                wave_lds_sync(); // (lane 0 overwrites columns other lanes just cleared)
                 if (lane == 0) { sg[0][0] = 1; sg[1][0] = 1; sg[2][0] = 1; sg[2][1] = S[0]; }
+                wave_lds_sync();
                 int dg_row = S[0] ? 1 : 0; // degree of the current row (uniform)
                 int row = 2;
                 while (row <= t) {
@@ -230,6 +239,7 @@ __global__ __launch_bounds__(kBchThreads) void bch_decode_kernel(BchArgs a)
                     if (lane == row + 1) dg_l = dg_next;
                     dg_row = dg_next;
                     row++;
+                    wave_lds_sync(); // row `row` is complete before any lane reads it (its own column, or sg[row_rho][src] later)
                 }
                 if (lane == 0) {
                 const int deg = dg_row;
@@ -322,7 +332,8 @@ BchDecoderHip::BchDecoderHip(int m, uint32_t prim_poly, int t, int n, int max_fr
     if (code_.n % 8 || code_.k % 8) { err_ = "u8 array messages are only supported for n and k multiple of 8."; return; } // lib/bch.cc:19-24
     if (max_frames_ < 1 || max_frames_ > 65535) { err_ = "max_frames must be in 1..65535 (frames are one launch dimension)"; return; }
 #define HIP_OK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { err_ = std::string(#x) + ": " + hipGetErrorString(e_); return; } } while (0)
-    HIP_OK(hipSetDevice(device_));
+    DeviceGuard dev_guard(device_); // restored on return (device_guard.h)
+    if (!dev_guard.ok) { err_ = "hipSetDevice failed"; return; }
     hipDeviceProp_t pr;
     HIP_OK(hipGetDeviceProperties(&pr, device_));
     n_cus_ = pr.multiProcessorCount;
@@ -370,7 +381,7 @@ int BchDecoderHip::set_descramble(bool enable)
 
 BchDecoderHip::~BchDecoderHip()
 {
-    (void)hipSetDevice(device_);
+    DeviceGuard dev_guard(device_);
     (void)hipFree(d_scramble_);
     (void)hipFree(d_antilog_); (void)hipFree(d_log_); (void)hipFree(d_quad_);
 }

@@ -230,10 +230,26 @@ int dvbs2_ldpc_decode(dvbs2_ldpc_t* h, const int8_t* llr_in, int n_frames, int m
     if (!h->d_bits) HCHK(hipMalloc(&h->d_bits, mf * (N / 8)));
     if (!h->d_llr) HCHK(hipMalloc(&h->d_llr, mf * N));
     if (!h->d_ret) HCHK(hipMalloc(&h->d_ret, ((mf + G - 1) / G + LdpcDecoderHip::kSlots) * 4));
-    if (!h->p_bits) HCHK(hipHostMalloc(&h->p_bits, mf * (N / 8)));
-    if (!h->p_ret) HCHK(hipHostMalloc(&h->p_ret, ((mf + G - 1) / G + LdpcDecoderHip::kSlots) * 4));
-    if (llr_out && !h->p_llr) HCHK(hipHostMalloc(&h->p_llr, mf * N));
     const size_t out_bytes = (out_mode ? h->dec->out_bits_message() : (int)N) / 8;
+    // Results land where the DMA engine can write them: straight in the caller's buffer when it is page-locked (hipHostMalloc'ed, or
+    // registered once with dvbs2_host_register -- what a block does with its item buffers), else in a pinned buffer of the handle
+    // that is copied out when the chunk has finished.
+    auto page_locked = [](const void* p, size_t bytes) {
+        if (!p || !bytes) return false;
+        hipPointerAttribute_t a0{}, a1{};
+        if (hipPointerGetAttributes(&a0, p) != hipSuccess || hipPointerGetAttributes(&a1, (const char*)p + bytes - 1) != hipSuccess) {
+            (void)hipGetLastError(); // an ordinary pageable pointer: not an error of this call
+            return false;
+        }
+        return a0.type == hipMemoryTypeHost && a1.type == hipMemoryTypeHost;
+    };
+    const size_t n_groups = ((size_t)n_frames + G - 1) / G;
+    uint8_t* bits_land = page_locked(bits_out, (size_t)n_frames * out_bytes) ? bits_out : nullptr;
+    int8_t* llr_land = page_locked(llr_out, (size_t)n_frames * N) ? llr_out : nullptr;
+    int32_t* ret_land = page_locked(ret, n_groups * 4) ? ret : nullptr;
+    if (!bits_land) { if (!h->p_bits) HCHK(hipHostMalloc(&h->p_bits, mf * (N / 8))); bits_land = h->p_bits; }
+    if (ret && !ret_land) { if (!h->p_ret) HCHK(hipHostMalloc(&h->p_ret, ((mf + G - 1) / G + LdpcDecoderHip::kSlots) * 4)); ret_land = h->p_ret; }
+    if (llr_out && !llr_land) { if (!h->p_llr) HCHK(hipHostMalloc(&h->p_llr, mf * N)); llr_land = h->p_llr; }
     // Chunks of whole groups (an even number of frames: two frames per workgroup) of at least 512 frames -- one frame pair
     // per CU; a smaller launch takes just as long -- and about an eighth of the call: the host-to-device copy of chunk
     // c + 1 and the device-to-host copies of chunk c - 1 run under the decode of chunk c. Chunk c uses slot and stream
@@ -246,9 +262,9 @@ int dvbs2_ldpc_decode(dvbs2_ldpc_t* h, const int8_t* llr_in, int n_frames, int m
     auto copy_out = [&](int c) -> int {
         const int f0 = c * chunk, nf = std::min(chunk, n_frames - f0);
         hipStream_t st = h->stream[c % LdpcDecoderHip::kSlots];
-        HCHK(hipMemcpyAsync(h->p_bits + (size_t)f0 * out_bytes, h->d_bits + (size_t)f0 * out_bytes, (size_t)nf * out_bytes, hipMemcpyDeviceToHost, st));
-        if (llr_out) HCHK(hipMemcpyAsync(h->p_llr + (size_t)f0 * N, h->d_llr + (size_t)f0 * N, (size_t)nf * N, hipMemcpyDeviceToHost, st));
-        if (ret) HCHK(hipMemcpyAsync(h->p_ret + f0 / G, h->d_ret + f0 / G, (size_t)((nf + G - 1) / G) * 4, hipMemcpyDeviceToHost, st));
+        HCHK(hipMemcpyAsync(bits_land + (size_t)f0 * out_bytes, h->d_bits + (size_t)f0 * out_bytes, (size_t)nf * out_bytes, hipMemcpyDeviceToHost, st));
+        if (llr_out) HCHK(hipMemcpyAsync(llr_land + (size_t)f0 * N, h->d_llr + (size_t)f0 * N, (size_t)nf * N, hipMemcpyDeviceToHost, st));
+        if (ret) HCHK(hipMemcpyAsync(ret_land + f0 / G, h->d_ret + f0 / G, (size_t)((nf + G - 1) / G) * 4, hipMemcpyDeviceToHost, st));
         return DVBS2_OK;
     };
     auto finish = [&](int c) -> int {
@@ -257,23 +273,29 @@ int dvbs2_ldpc_decode(dvbs2_ldpc_t* h, const int8_t* llr_in, int n_frames, int m
         if (r > 0) { if (int rc = copy_out(c)) return rc; } // outputs rewritten by the extra rounds: fetch them again
         HCHK(hipStreamSynchronize(h->stream[c % LdpcDecoderHip::kSlots]));
         const int f0 = c * chunk, nf = std::min(chunk, n_frames - f0);
-        std::memcpy(bits_out + (size_t)f0 * out_bytes, h->p_bits + (size_t)f0 * out_bytes, (size_t)nf * out_bytes);
-        if (llr_out) std::memcpy(llr_out + (size_t)f0 * N, h->p_llr + (size_t)f0 * N, (size_t)nf * N);
-        if (ret) std::memcpy(ret + f0 / G, h->p_ret + f0 / G, (size_t)((nf + G - 1) / G) * 4);
+        if (bits_land != bits_out) std::memcpy(bits_out + (size_t)f0 * out_bytes, bits_land + (size_t)f0 * out_bytes, (size_t)nf * out_bytes);
+        if (llr_out && llr_land != llr_out) std::memcpy(llr_out + (size_t)f0 * N, llr_land + (size_t)f0 * N, (size_t)nf * N);
+        if (ret && ret_land != ret) std::memcpy(ret + f0 / G, ret_land + f0 / G, (size_t)((nf + G - 1) / G) * 4);
         return DVBS2_OK;
     };
-    for (int c = 0; c < n_chunks; c++) {
-        if (c >= LdpcDecoderHip::kSlots) if (int rc = finish(c - LdpcDecoderHip::kSlots)) return rc;
-        const int f0 = c * chunk, nf = std::min(chunk, n_frames - f0);
-        hipStream_t st = h->stream[c % LdpcDecoderHip::kSlots];
-        HCHK(hipMemcpyAsync(h->d_in + (size_t)f0 * N, llr_in + (size_t)f0 * N, (size_t)nf * N, hipMemcpyHostToDevice, st));
-        if (h->dec->enqueue(h->d_in + (size_t)f0 * N, nf, max_trials, out_mode, h->d_bits + (size_t)f0 * out_bytes,
-                            llr_out ? h->d_llr + (size_t)f0 * N : nullptr, h->d_ret + f0 / G, st, c % LdpcDecoderHip::kSlots, f0))
-            return fail(DVBS2_EDEVICE, h->dec->error());
-        if (int rc = copy_out(c)) return rc;
-    }
-    for (int c = std::max(0, n_chunks - LdpcDecoderHip::kSlots); c < n_chunks; c++) if (int rc = finish(c)) return rc;
-    return DVBS2_OK;
+    // (a failure in the middle of the pipeline must not leave chunks in flight or slots busy: the handle stays usable)
+    auto run = [&]() -> int {
+        for (int c = 0; c < n_chunks; c++) {
+            if (c >= LdpcDecoderHip::kSlots) if (int rc = finish(c - LdpcDecoderHip::kSlots)) return rc;
+            const int f0 = c * chunk, nf = std::min(chunk, n_frames - f0);
+            hipStream_t st = h->stream[c % LdpcDecoderHip::kSlots];
+            HCHK(hipMemcpyAsync(h->d_in + (size_t)f0 * N, llr_in + (size_t)f0 * N, (size_t)nf * N, hipMemcpyHostToDevice, st));
+            if (h->dec->enqueue(h->d_in + (size_t)f0 * N, nf, max_trials, out_mode, h->d_bits + (size_t)f0 * out_bytes,
+                                llr_out ? h->d_llr + (size_t)f0 * N : nullptr, h->d_ret + f0 / G, st, c % LdpcDecoderHip::kSlots, f0))
+                return fail(DVBS2_EDEVICE, h->dec->error());
+            if (int rc = copy_out(c)) return rc;
+        }
+        for (int c = std::max(0, n_chunks - LdpcDecoderHip::kSlots); c < n_chunks; c++) if (int rc = finish(c)) return rc;
+        return DVBS2_OK;
+    };
+    const int rc = run();
+    if (rc != DVBS2_OK) h->dec->abort_all();
+    return rc;
     API_CATCH
 }
 
@@ -628,7 +650,9 @@ static int chain_enqueue_tail(dvbs2_chain_t* h, const int8_t* d_llr, const Demap
     if (h->ldpc->dec->enqueue(d_llr, n_frames, max_trials, DVBS2_OM_MESSAGE, nullptr, nullptr, d_ldpc_ret, (hipStream_t)stream, 0, 0, dm))
         return fail(DVBS2_EDEVICE, h->ldpc->dec->error());
     h->pending = true; h->n_frames = n_frames; h->d_msg = d_msg; h->d_bch_corr = d_bch_corr ? d_bch_corr : h->d_corr; h->stream = stream;
-    return chain_bch(h);
+    const int rc = chain_bch(h);
+    if (rc != DVBS2_OK) { h->ldpc->dec->abort_all(); h->pending = false; } // nothing stays in flight or busy after a failed call
+    return rc;
 }
 
 extern "C" {

@@ -54,6 +54,9 @@ public:
     const uint8_t* state() const { return d_state_; } // per frame N offset-binary LLR bytes, information part in natural order
 
     int finish(int slot = 0); // 0 = done, 1 = done and the outputs were rewritten by extra rounds, -1 = error
+    // error paths of the callers: wait for whatever is in flight on every slot and free the slots (results are discarded; the
+    // error text of the failed call is kept)
+    void abort_all();
     int decode_device(const int8_t* d_llr_in, int n_frames, int max_trials, int out_mode,
                       uint8_t* d_bits_out, int8_t* d_llr_out, int32_t* d_ret, hipStream_t stream);
 

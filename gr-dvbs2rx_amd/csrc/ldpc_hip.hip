@@ -101,7 +101,8 @@ LdpcDecoderHip::LdpcDecoderHip(const LdpcTableDesc* table, int out_bits_message,
     dmax_ = pr_ ? 8 : std::max(4, (degmax + 3) / 4 * 4);
     if (degmin < 3 || degmin <= dmax_ - 8) { err_ = "check degree spread unsupported by the kernel variants"; return; }
     words_per_check_ = dmax_ / 4;
-    HIP_OK(hipSetDevice(device_));
+    DeviceGuard dev_guard(device_); // the caller's current device is restored when the constructor returns (device_guard.h)
+    if (!dev_guard.ok) { err_ = "hipSetDevice failed"; return; }
     const int RS = rec_stride(dmax_);
     std::vector<uint32_t> hr((size_t)sched_.q * RS, 0);
     // Which build of the sweep kernel: measured per table (ldpc_policy.inc <- tools/policy_sweep.py + tools/gen_policy.py); a table
@@ -324,7 +325,7 @@ LdpcDecoderHip::LdpcDecoderHip(const LdpcTableDesc* table, int out_bits_message,
 
 LdpcDecoderHip::~LdpcDecoderHip()
 {
-    (void)hipSetDevice(device_);
+    DeviceGuard dev_guard(device_);
     (void)hipFree(d_recs_); (void)hipFree(d_wrecs_); (void)hipFree(d_cu_slots_); (void)hipFree(d_state_); (void)hipFree(d_msgs_);
     (void)hipFree(d_iters_); (void)hipFree(d_good_); (void)hipFree(d_target_); (void)hipFree(d_flag_);
     if (h_flag_) (void)hipHostFree(h_flag_);
@@ -388,13 +389,15 @@ int LdpcDecoderHip::enqueue(const int8_t* d_llr_in, int n_frames, int max_trials
     if (frame_base % 2 || (frame_base && frame_base % G_)) { call_err_ = "frame_base must be a multiple of the group size and even"; return -1; }
     if (max_trials < 0) { call_err_ = "max_trials < 0"; return -1; }
     Pending& p = pend_[slot];
+    // a call that fails below leaves the slot free again (the handle stays usable: "a failed call does not disable the handle")
+    struct Release { Pending& p; bool armed = true; ~Release() { if (armed) p.active = false; } } release{ p };
     p.active = true; p.n_frames = n_frames; p.max_trials = max_trials; p.out_mode = out_mode; p.frame_base = frame_base;
     p.bits = d_bits_out; p.llr_out = d_llr_out; p.ret = d_ret; p.stream = stream;
     h_flag_[slot] = 0;
-    if (n_frames == 0) return 0;
+    if (n_frames == 0) { release.armed = false; return 0; }
     DeviceGuard dev_guard(device_);
-    if (!dev_guard.ok) { p.active = false; call_err_ = "hipSetDevice failed"; return -1; }
-    if (dm && dm->mode && pr_) { p.active = false; call_err_ = "this sweep kernel does not demap while loading"; return -1; }
+    if (!dev_guard.ok) { call_err_ = "hipSetDevice failed"; return -1; }
+    if (dm && dm->mode && pr_) { call_err_ = "this sweep kernel does not demap while loading"; return -1; }
     launch_sweep(d_llr_in, false, 1, n_frames, max_trials, frame_base, stream, dm);
     if (d_tdbg_) {
         HIP_RET(hipStreamSynchronize(stream));
@@ -428,6 +431,7 @@ int LdpcDecoderHip::enqueue(const int8_t* d_llr_in, int n_frames, int max_trials
     launch_finalize(p);
     HIP_RET(hipMemcpyAsync(h_flag_ + slot, d_flag_ + slot, 4, hipMemcpyDeviceToHost, stream));
     HIP_RET(hipGetLastError());
+    release.armed = false;
     return 0;
 }
 
@@ -454,6 +458,15 @@ int LdpcDecoderHip::finish(int slot)
     HIP_RET(hipGetLastError());
     HIP_RET(hipStreamSynchronize(p.stream));
     return 1; // outputs were rewritten after the stream's first completion
+}
+
+void LdpcDecoderHip::abort_all()
+{
+    DeviceGuard dev_guard(device_);
+    for (Pending& p : pend_) {
+        if (p.active && p.n_frames > 0 && dev_guard.ok) (void)hipStreamSynchronize(p.stream);
+        p.active = false;
+    }
 }
 
 int LdpcDecoderHip::decode_device(const int8_t* d_llr_in, int n_frames, int max_trials, int out_mode,

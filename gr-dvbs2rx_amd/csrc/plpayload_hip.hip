@@ -56,11 +56,12 @@ PlPayloadHip::PlPayloadHip(int gold_code, int n_slots, int has_pilots, int max_f
     if (max_frames_ < 1 || max_frames_ > 65535) { err_ = "max_frames must be in 1..65535 (frames are one launch dimension)"; return; }
     std::vector<uint8_t> rn(payload_len());
     pl_scrambling_rn(gold_code, rn.data(), (int)rn.size());
-    if (hipSetDevice(device_) != hipSuccess || hipMalloc(&d_rn_, rn.size()) != hipSuccess ||
+    DeviceGuard dev_guard(device_); // the caller's current device is restored on return
+    if (!dev_guard.ok || hipMalloc(&d_rn_, rn.size()) != hipSuccess ||
         hipMemcpy(d_rn_, rn.data(), rn.size(), hipMemcpyHostToDevice) != hipSuccess) { err_ = "device setup failed"; return; }
 }
 
-PlPayloadHip::~PlPayloadHip() { (void)hipSetDevice(device_); (void)hipFree(d_rn_); }
+PlPayloadHip::~PlPayloadHip() { DeviceGuard dev_guard(device_); (void)hipFree(d_rn_); }
 
 int PlPayloadHip::process_device(const float* d_payload, int n_frames, const float* d_plheader_phase, const float* d_phase_inc,
                                  const int32_t* d_coarse_corrected, const float* d_pilot_phase, float* d_out, hipStream_t stream)

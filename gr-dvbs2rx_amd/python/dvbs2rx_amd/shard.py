@@ -66,6 +66,17 @@ def sum_over_ranks(value, device=None):
     return float(t.item())
 
 
+def gather_over_ranks(value, device=None):
+    """One float per rank, in rank order, on every rank (bench.py: per-rank rates and their spread)."""
+    if not dist.is_initialized():
+        return [float(value)]
+    world = dist.get_world_size()
+    t = torch.zeros(world, dtype=torch.float64, device=_reduce_device(device))
+    t[dist.get_rank()] = float(value)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return [float(x) for x in t.cpu().tolist()]
+
+
 def finalize():
     if dist.is_initialized():
         dist.destroy_process_group()

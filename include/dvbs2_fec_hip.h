@@ -210,19 +210,6 @@ int dvbs2_chain_set_descramble(dvbs2_chain_t* h, int enable);
 int dvbs2_chain_decode_device(dvbs2_chain_t* h, const float* d_syms, int n_frames, const float* d_n0, int n0_count,
                               int max_trials, uint8_t* d_msg, int32_t* d_ldpc_ret, int32_t* d_bch_corr, void* stream);
 
-/* ---- upstream neighbour (SURVEY 8(f)-3): the PLFRAME payload step of plsync_cc_impl::handle_payload()
- * (reference lib/plsync_cc_impl.cc:644-653, :727-795): PL descrambling (lib/pl_descrambler.cc:36-105), pilot
- * block removal (:480-485) and phase de-rotation, restarted at every 16-slot segment of a coarse-corrected frame
- * from the preceding pilot block's phase estimate (:759-763). What stays in the block: frame/frequency
- * synchronisation, i.e. everything that PRODUCES the per-frame parameters below.
- * gold_code   PL scrambling code n (0 .. 2^18-2); n_slots 36..360 (lib/pl_signaling.cc:28-48)
- * payload     n_frames * payload_len complex symbols (re, im), payload_len = 90 n_slots + 36 n_pilots,
- *             n_pilots = has_pilots ? (n_slots - 1) / 16 : 0 (lib/pl_signaling.cc:51-60)
- * plheader_phase[f], phase_inc[f] = 2 pi fine_foffset (used only when coarse_corrected[f] != 0, :730-732),
- * pilot_phase[f * n_pilots + i] = pl_freq_sync::get_pilot_phase(i)
- * xfecframes  n_frames * 90 n_slots complex symbols: the input of dvbs2_demap_soft
- * The rotator is a float recurrence in the reference (VOLK); here the phase of every symbol is evaluated directly:
- * equal within 1e-4 absolute per component for unit-energy symbols, not bit-exact. */
 /* d_llr: n_frames * N int8 LLRs (works on chains of either kind) */
 int dvbs2_chain_decode_llr_device(dvbs2_chain_t* h, const int8_t* d_llr, int n_frames, int max_trials, uint8_t* d_msg,
                                   int32_t* d_ldpc_ret, int32_t* d_bch_corr, void* stream);
@@ -237,6 +224,19 @@ int dvbs2_chain_finish(dvbs2_chain_t* h);
 int dvbs2_chain_ldpc_profile(dvbs2_chain_t* h, int enable, double* total_ms, int* launches);
 const char* dvbs2_chain_ldpc_kernel_name(const dvbs2_chain_t* h);
 
+/* ---- upstream neighbour (SURVEY 8(f)-3): the PLFRAME payload step of plsync_cc_impl::handle_payload()
+ * (reference lib/plsync_cc_impl.cc:644-653, :727-795): PL descrambling (lib/pl_descrambler.cc:36-105), pilot
+ * block removal (:480-485) and phase de-rotation, restarted at every 16-slot segment of a coarse-corrected frame
+ * from the preceding pilot block's phase estimate (:759-763). What stays in the block: frame/frequency
+ * synchronisation, i.e. everything that PRODUCES the per-frame parameters below.
+ * gold_code   PL scrambling code n (0 .. 2^18-2); n_slots 36..360 (lib/pl_signaling.cc:28-48)
+ * payload     n_frames * payload_len complex symbols (re, im), payload_len = 90 n_slots + 36 n_pilots,
+ *             n_pilots = has_pilots ? (n_slots - 1) / 16 : 0 (lib/pl_signaling.cc:51-60)
+ * plheader_phase[f], phase_inc[f] = 2 pi fine_foffset (used only when coarse_corrected[f] != 0, :730-732),
+ * pilot_phase[f * n_pilots + i] = pl_freq_sync::get_pilot_phase(i)
+ * xfecframes  n_frames * 90 n_slots complex symbols: the input of dvbs2_demap_soft
+ * The rotator is a float recurrence in the reference (VOLK); here the phase of every symbol is evaluated directly:
+ * equal within 1e-4 absolute per component for unit-energy symbols, not bit-exact. */
 typedef struct dvbs2_plpayload dvbs2_plpayload_t;
 int dvbs2_plpayload_create(dvbs2_plpayload_t** h, int gold_code, int n_slots, int has_pilots, int max_frames, int device);
 void dvbs2_plpayload_destroy(dvbs2_plpayload_t* h);

@@ -12,11 +12,10 @@
  *   error-location numbers  lib/bch.cc:307-385 (+ Chien: lib/gf.cc:290-404)
  *   correction / decode     lib/bch.cc:429-452, :468-487
  *
- * The reference's BCH sources are NOT buildable in this image without a stand-in for
- * <gnuradio/attributes.h>, so there is no oracle/_ref for BCH. Parity pin = the reference's own
- * known-answer tests (lib/qa_bch.cc, lib/qa_gf.cc) transcribed as data in tests/golden/bch_kat.json
- * (tests/test_oracle_bch.py). Behaviour beyond t errors (partial corrections, return -1, the
- * exceptions the reference would throw) is restated from the cited lines.
+ * Pinned three ways: the reference's own known-answer tests (lib/qa_bch.cc, lib/qa_gf.cc)
+ * transcribed as data in tests/golden/bch_kat.json; digests of the GENUINE codec (oracle/_ref/libdvbs2_ref_bch.so =
+ * lib/bch.cc + lib/gf.cc compiled where they lie, oracle/Makefile) in tests/golden/bch_golden.json, including words
+ * crafted to reach both throw sites; and live against that library (tests/test_oracle_kat.py).
  *
  * Return convention of oracle_bch_decode_bytes: >=0 corrected count, -1 failure (as the reference),
  * -2 = the reference would have thrown (std::out_of_range from galois_field::get_exponent(0), lib/gf.h:110,

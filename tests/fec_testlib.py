@@ -177,6 +177,34 @@ def ref_ldpc_decode(table, llr, impl, trials):
     return out, rets
 
 
+def ref_ldpc_decode_parallel(table, llr, impl, trials, procs=None):
+    """Genuine reference on a WHOLE batch: worker processes (tools/cpu_ref_decode_worker.py), each decoding a contiguous
+    range of groups of a shared .npy file in /dev/shm. Returns (decoded llr, list of return values per group), identical
+    to ref_ldpc_decode(). n_frames must be a multiple of the reference's batch (32 for AVX2, 16 otherwise)."""
+    import sys
+    import tempfile
+    G = 32 if impl == 0 else 16
+    nf = llr.shape[0]
+    assert nf % G == 0, "whole reference batches only"
+    ng = nf // G
+    if procs is None:
+        procs = max(1, min(len(os.sched_getaffinity(0)), 64, ng))
+    if procs == 1 or ng < 4:
+        return ref_ldpc_decode(table, llr, impl, trials)
+    tmp = "/dev/shm" if os.path.isdir("/dev/shm") else None
+    with tempfile.TemporaryDirectory(dir=tmp) as d:
+        f_llr, f_ret = os.path.join(d, "llr.npy"), os.path.join(d, "ret.npy")
+        np.save(f_llr, np.ascontiguousarray(llr, np.int8))
+        np.save(f_ret, np.zeros(ng, np.int32))
+        worker = os.path.join(ROOT, "tools", "cpu_ref_decode_worker.py")
+        cuts = [ng * i // procs for i in range(procs + 1)]
+        ps = [subprocess.Popen([sys.executable, worker, table, str(impl), str(trials), f_llr, f_ret, str(cuts[i]), str(cuts[i + 1])])
+              for i in range(procs) if cuts[i + 1] > cuts[i]]
+        for p in ps:
+            assert p.wait() == 0, "reference worker failed"
+        return np.load(f_llr), np.load(f_ret).tolist()
+
+
 def pack_bits(llr, nbits):
     """Hard decision + MSB-first packing (lib/ldpc_decoder_bb_impl.cc:432-442)."""
     out = np.zeros((llr.shape[0], nbits // 8), np.uint8)
@@ -299,6 +327,26 @@ def bch_golden_input(codec, n, k, case):
     msg = np.random.default_rng(case["seed"]).integers(0, 256, (1, k // 8), dtype=np.uint8)
     cw = codec.encode(msg)[0] if hasattr(codec, "encode") else codec.encode_bytes(msg)[0]
     return flip_bits(cw, case["flips"])
+
+
+def chain_expect(table, bch_n, bch_t, framesize, llr, trials):
+    """What ldpc_decoder_bb (OM_MESSAGE) -> bch_decoder_bb give for a WHOLE batch of int8 LLR frames, G = 32: the genuine
+    AVX2 LDPC reference on all cores (the restatement without oracle/_ref), then the BCH codec frame by frame (the genuine
+    bch.cc when oracle/_ref holds it, else the restatement). Returns (messages, corrections per frame, LDPC return values,
+    who)."""
+    if ref_ldpc() is not None:
+        dec_llr, wret = ref_ldpc_decode_parallel(table, llr, 0, trials); who = "reference AVX2 LDPC"
+    else:
+        dec_llr, wret = oracle_ldpc_decode(table, llr, 32, trials); who = "oracle LDPC"
+    cw = pack_bits(dec_llr, bch_n)
+    m, prim = BCH_FIELDS[framesize]
+    if ref_bch() is not None:
+        rb = RefBch(prim, bch_t, bch_n)
+        msg, corr = rb.decode(cw)
+        rb.close()
+        return msg, np.asarray(corr, np.int32), wret, who + " + reference BCH"
+    msg, corr = OracleBch(m, prim, bch_t, bch_n).decode_bytes(cw)
+    return msg, corr, wret, who + " + BCH oracle"
 
 
 BCH_FIELDS = {1: (16, 0b10000000000101101), 0: (14, 0b100000000101011), 2: (15, 0b1000000000101101)}  # by framesize id

@@ -359,3 +359,47 @@ def test_chain_from_llrs(rate):
     chain.finish()
     assert torch.equal(d_msg, d_msg2)
     chain.close()
+
+
+# ------------------------------------------------------------------ BASELINE configs 3 and 5 at full size, the benchmark's own input
+@pytest.mark.parametrize("config", ["config3", "config5", "config5_s2x"])
+def test_full_batch_chains_vs_reference(config):
+    """4096 frames of bench.py's never-converging input (same generators and seeds) through the chains, EVERY frame against the
+    CPU chain: (demapper restatement ->) genuine AVX2 LDPC on all host cores -> BCH codec; messages, BCH results per frame and LDPC
+    return values per group. config3: 8PSK 3/4 normal from noise symbols (demapper fused into the sweep kernel's load, B7,
+    BCH(48600,48408,12)); config5: 9/10 normal from LLRs (B11 + BCH(58320,58192,8)); config5_s2x: 154/180 (S2X B21 + BCH t = 12)."""
+    import torch
+    nf, G, cap = 4096, 32, 50
+    rate = {"config3": "C3_4", "config5": "C9_10", "config5_s2x": "C154_180"}[config]
+    fi = get_fec_info(capi.STANDARD_DVBS2, capi.FECFRAME_NORMAL, rate)
+    st = torch.cuda.current_stream().cuda_stream
+    d_ret = torch.empty(nf // G, dtype=torch.int32, device="cuda")
+    d_corr = torch.empty(nf, dtype=torch.int32, device="cuda")
+    if config == "config3":
+        chain = FecChain(rate=rate, constellation=capi.MOD_8PSK, group_size=G, max_frames=nf, max_trials=cap)
+        g = torch.Generator(device="cuda"); g.manual_seed(777)
+        syms = torch.randn((nf, chain.n_syms * 2), generator=g, device="cuda") * 0.7071
+        n0 = torch.tensor([1.0], dtype=torch.float32, device="cuda")
+        d_msg = torch.empty((nf, chain.msg_bytes), dtype=torch.uint8, device="cuda")
+        chain.work_device(syms.data_ptr(), nf, n0.data_ptr(), 1, d_msg.data_ptr(), d_ret.data_ptr(), d_corr.data_ptr(), st)
+        llr = T.oracle_demap(syms.cpu().numpy().view(np.complex64), np.float32(1.0), 8, 0)
+    else:
+        chain = FecChain(rate=rate, group_size=G, max_frames=nf, max_trials=cap, from_llr=True)
+        g = torch.Generator(device="cuda"); g.manual_seed(888)
+        d_llr = torch.clamp(torch.round(torch.randn((nf, chain.n_llr), generator=g, device="cuda") * 8.0), -128, 127).to(torch.int8)
+        d_msg = torch.empty((nf, chain.msg_bytes), dtype=torch.uint8, device="cuda")
+        chain.work_llr_device(d_llr.data_ptr(), nf, d_msg.data_ptr(), d_ret.data_ptr(), d_corr.data_ptr(), st)
+        llr = d_llr.cpu().numpy()
+    if T.ref_ldpc() is None:   # no prebuilt reference here: the restatement on the last two groups
+        sl = slice(nf - 64, nf)
+        want_msg, want_corr, wret, _ = T.chain_expect(fi["table"], fi["bch_n"], fi["bch_t"], capi.FECFRAME_NORMAL, llr[sl], cap)
+        assert d_ret[-2:].cpu().tolist() == wret and d_corr[sl].cpu().numpy().tolist() == want_corr.tolist()
+        assert np.array_equal(d_msg[sl].cpu().numpy(), want_msg)
+    else:
+        want_msg, want_corr, wret, _ = T.chain_expect(fi["table"], fi["bch_n"], fi["bch_t"], capi.FECFRAME_NORMAL, llr, cap)
+        assert d_ret.cpu().tolist() == wret
+        assert d_corr.cpu().numpy().tolist() == want_corr.tolist()
+        got = d_msg.cpu().numpy()
+        bad = np.nonzero((got != want_msg).any(axis=1))[0]
+        assert bad.size == 0, f"{config}: {bad.size} frames differ, first {bad[:8]}"
+    chain.close()

@@ -305,13 +305,14 @@ def test_full_batch_properties(table, nf, trials, amp, sigma):
 
 
 def test_async_entry_and_chunked_host_path(monkeypatch):
-    """dvbs2_ldpc_enqueue_device + dvbs2_ldpc_finish == dvbs2_ldpc_decode_device; the host entry (chunks of whole groups
-    on two streams) == the device entry; and with no device-side resolution rounds enqueued (DVBS2_RESOLVE_ROUNDS=0) the
+    """dvbs2_ldpc_enqueue_device + dvbs2_ldpc_finish == dvbs2_ldpc_decode_device; the host entry == the device entry (416 frames
+    are ONE chunk of the default host pipeline: chunk = max(512, n_frames / 8); the multi-chunk pipeline is
+    test_host_entry_multi_chunk); and with no device-side resolution rounds enqueued (DVBS2_RESOLVE_ROUNDS=0) the
     host-side leftover rounds of finish() give the same result (near-threshold input: groups need resume passes)."""
     import torch
     table = "S2_TABLE_C1"
     N, K, _, _ = T.ldpc_info(table)
-    nf, G, cap = 416, 32, 25  # 13 groups: the host path splits it into chunks of 128 frames
+    nf, G, cap = 416, 32, 25  # 13 groups
     llr, _ = T.llr_codeword_awgn(table, nf, 2025, amp=5, sigma=6.0)
     want, wret = checker(table, llr, G, cap)
     assert len(set(wret)) > 2  # groups stop at different counts: the stopping rule is exercised
@@ -382,3 +383,135 @@ def test_enqueue_finish_contract():
     dec.work_device(d_in.data_ptr(), nf, d_bits.data_ptr(), 0, d_ret.data_ptr(), st)  # the handle still works
     assert np.array_equal(d_bits.cpu().numpy(), T.pack_bits(want, K))
     dec.close()
+
+
+@pytest.mark.parametrize("nf,chunk,rounds", [(416, "64", None), (416, "64", "0"), (1088, None, None), (1088, None, "0"), (200, "66", "0")])
+def test_host_entry_multi_chunk(monkeypatch, nf, chunk, rounds):
+    """The chunked pipeline of the host-buffer entry dvbs2_ldpc_decode (csrc/c_api.hip): frame_base > 0, all four slots and
+    streams, slot re-use after finish(c - kSlots) (seven chunks of 64 frames), the pinned landing buffers, and -- with no
+    device-side resolution rounds (DVBS2_RESOLVE_ROUNDS=0) on near-threshold input -- the re-fetch of a chunk's outputs when
+    finish() had to run host-driven rounds. 1088 frames take the DEFAULT chunking (512 + 512 + 64); chunk 66 with G = 32 is
+    rounded up to whole groups (96). Against the genuine reference on the whole batch."""
+    if chunk is not None:
+        monkeypatch.setenv("DVBS2_HOST_CHUNK", chunk)
+    if rounds is not None:
+        monkeypatch.setenv("DVBS2_RESOLVE_ROUNDS", rounds)
+    table, G, cap = "S2_TABLE_C1", 32, 25
+    N, K, _, _ = T.ldpc_info(table)
+    base, _ = T.llr_codeword_awgn(table, 96, 2026, amp=5, sigma=6.0)
+    llr = np.tile(base, ((nf + 95) // 96, 1))[:nf].copy()
+    llr[nf // 2] = T.llr_noise(1, N, 4)[0]              # one hopeless frame: its group runs to the cap
+    tail = nf % G
+    want, wret = checker(table, llr[:nf - tail], G, cap)
+    if tail:
+        w2, r2 = T.oracle_ldpc_decode(table, llr[nf - tail:], tail, cap)
+        want, wret = np.concatenate([want, w2]), wret + r2
+    assert len(set(wret)) > 2
+    dec = LdpcDecoder(table=table, message_bits=K, group_size=G, max_frames=nf, max_trials=cap, outputmode=capi.OM_MESSAGE)
+    for _ in range(2):                                   # the second call re-uses every slot, stream and landing buffer
+        bits, out, ret = dec.work(llr, want_llr=True)
+        assert ret.tolist() == wret
+        assert np.array_equal(out, want) and np.array_equal(bits, T.pack_bits(want, K))
+    bits, _, ret = dec.work(llr)                         # without the soft output (no llr landing buffer in the copies)
+    assert ret.tolist() == wret and np.array_equal(bits, T.pack_bits(want, K))
+    dec.close()
+
+
+def test_baseline_config1_one_frame_replicated():
+    """BASELINE.json config 1 ("QPSK 1/2 normal FECFRAME, 50 iters, 1 frame ... plumbing"), SURVEY 8(d) row 1: ONE frame
+    replicated over the 32 lanes of a reference batch -- all lanes identical, so group semantics = single-frame semantics --
+    through the host-buffer entry dvbs2_ldpc_decode (what ldpc_decoder_bb's general_work would call,
+    lib/ldpc_decoder_bb_impl.cc:406-449), created by (standard, framesize, rate) like the block, cap 50; decoded LLRs, packed
+    message bits and the return value against the genuine AVX2 decoder (lib/ldpc_decoder/layered_decoder.hh:143-160).
+    Three frames: one that converges after several updates, a clean codeword (no update), noise (runs the cap, ret -1)."""
+    table = "S2_TABLE_B4"
+    N, K, _, _ = T.ldpc_info(table)
+    near, cw = T.llr_codeword_awgn(table, 1, 31, amp=6, sigma=5.0)
+    clean, _ = T.llr_codeword_awgn(table, 1, 32, amp=20, sigma=0.0)
+    dec = LdpcDecoder(standard=capi.STANDARD_DVBS2, framesize=capi.FECFRAME_NORMAL, rate="C1_2", outputmode=capi.OM_MESSAGE,
+                      max_trials=50, group_size=32, max_frames=32)
+    assert dec.kernel_name.startswith("ldpc_layered")
+    seen = []
+    for frame in (near[0], clean[0], T.llr_noise(1, N, 33)[0]):
+        x = np.tile(frame, (32, 1))
+        bits, out, ret = dec.work(x, want_llr=True)
+        want, wret = checker(table, x, 32, 50)
+        assert ret.tolist() == wret
+        assert np.array_equal(out, want) and np.array_equal(bits, T.pack_bits(want, K))
+        assert (out == out[0]).all()                     # identical lanes stay identical
+        seen.append(wret[0])
+    assert 0 < seen[0] < 50 and seen[1] == 50 and seen[2] == -1, seen
+    assert np.array_equal(np.unpackbits(dec.work(np.tile(near[0], (32, 1)))[0][0]), cw[0, :K])
+    dec.close()
+
+
+def _torch_noise(nf, N, seed):
+    import torch
+    g = torch.Generator(device="cuda"); g.manual_seed(seed)
+    return torch.clamp(torch.round(torch.randn((nf, N), generator=g, device="cuda") * 8.0), -128, 127).to(torch.int8)
+
+
+@pytest.mark.parametrize("table,nf,trials,seed", [("S2_TABLE_B4", 4096, 50, 12345), ("S2_TABLE_C1", 16384, 25, 777)])
+def test_full_batch_of_the_benchmark_input_vs_reference(table, nf, trials, seed):
+    """BASELINE configs 2 and 4 at FULL size on the benchmark's own never-converging input (bench.py: same generator, same seed),
+    EVERY frame against the genuine AVX2 reference run on all host cores (tests/fec_testlib.ref_ldpc_decode_parallel): decoded
+    LLRs, packed bits, return values. Covers what the first-group gates cannot: high workgroup indices, the second half of every
+    pair workgroup, the one-frame builds' CU counters, several workgroups per CU in sequence."""
+    import torch
+    N, K, _, _ = T.ldpc_info(table)
+    d_in = _torch_noise(nf, N, seed)
+    dec = LdpcDecoder(table=table, message_bits=K, group_size=32, max_frames=nf, max_trials=trials, outputmode=capi.OM_MESSAGE)
+    d_bits = torch.empty((nf, K // 8), dtype=torch.uint8, device="cuda")
+    d_llr = torch.empty((nf, N), dtype=torch.int8, device="cuda")
+    d_ret = torch.empty(nf // 32, dtype=torch.int32, device="cuda")
+    dec.work_device(d_in.data_ptr(), nf, d_bits.data_ptr(), d_llr.data_ptr(), d_ret.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    x = d_in.cpu().numpy()
+    if T.ref_ldpc() is not None:
+        want, wret = T.ref_ldpc_decode_parallel(table, x, 0, trials)
+    else:                                                # no prebuilt reference here: the restatement on a slice of the batch
+        sl = slice(nf - 64, nf)
+        want, wret = T.oracle_ldpc_decode(table, x[sl], 32, trials)
+        assert np.array_equal(d_llr[sl].cpu().numpy(), want) and d_ret[-2:].cpu().tolist() == wret
+        dec.close()
+        return
+    assert d_ret.cpu().tolist() == wret == [-1] * (nf // 32)
+    got = d_llr.cpu().numpy()
+    bad = np.nonzero((got != want).any(axis=1))[0]
+    assert bad.size == 0, f"{table}: {bad.size} frames differ, first {bad[:8]}"
+    assert np.array_equal(d_bits.cpu().numpy(), T.pack_bits(want, K))
+    dec.close()
+
+
+def test_two_devices_from_one_process():
+    """one host thread + stream per GPU. Two handles on devices 0 and 1 driven from ONE process (the caller's
+    current device stays where it was, csrc/device_guard.h), each decoding its contiguous G-aligned share; together they equal
+    the unsharded decode. Skips on a box with fewer than two GPUs."""
+    import torch
+    if capi.lib.dvbs2_device_count() < 2:
+        pytest.skip("needs two HIP devices")
+    table, G, cap = "S2_TABLE_C1", 32, 25
+    N, K, _, _ = T.ldpc_info(table)
+    llr, _ = T.llr_codeword_awgn(table, 128, 77, amp=5, sigma=6.0)
+    want, wret = checker(table, llr, G, cap)
+    torch.cuda.set_device(0)
+    decs = [LdpcDecoder(table=table, message_bits=K, group_size=G, max_frames=64, max_trials=cap, outputmode=capi.OM_MESSAGE, device=d)
+            for d in (0, 1)]
+    assert torch.cuda.current_device() == 0              # create() on device 1 did not move the caller
+    bufs = []
+    for d, dec in enumerate(decs):
+        dev = torch.device("cuda", d)
+        x = torch.from_numpy(llr[64 * d:64 * d + 64]).to(dev)
+        b = torch.zeros((64, K // 8), dtype=torch.uint8, device=dev)
+        o = torch.zeros((64, N), dtype=torch.int8, device=dev)
+        r = torch.zeros(2, dtype=torch.int32, device=dev)
+        st = torch.cuda.Stream(device=dev)
+        dec.enqueue_device(x.data_ptr(), 64, b.data_ptr(), o.data_ptr(), r.data_ptr(), st.cuda_stream)  # both GPUs busy before either is waited for
+        bufs.append((x, b, o, r, st))
+    assert torch.cuda.current_device() == 0
+    for d, dec in enumerate(decs):
+        dec.finish()
+        x, b, o, r, st = bufs[d]
+        assert r.cpu().tolist() == wret[2 * d:2 * d + 2]
+        assert np.array_equal(o.cpu().numpy(), want[64 * d:64 * d + 64])
+        assert np.array_equal(b.cpu().numpy(), T.pack_bits(want[64 * d:64 * d + 64], K))
+        dec.close()

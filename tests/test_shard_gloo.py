@@ -35,6 +35,7 @@ def _worker(rank, world, port, q):
     shard.barrier_sync()
     dt = shard.max_over_ranks(1.0 + rank)           # slowest rank defines the step time
     frames = shard.sum_over_ranks(b - a)
+    assert shard.gather_over_ranks(10.0 + rank) == [10.0 + r for r in range(world)]  # per-rank rates, rank order
     q.put((rank, a, b, T.sha(out), ret, dt, frames))
     shard.finalize()
 

@@ -2,12 +2,15 @@
 """tools/gen_traffic.py <summary.txt of tools/profile_round.sh> -> profiles/traffic.json
 
 HBM bytes per launch of every BASELINE configuration's dominant kernel from the rocprofv3 PMC passes of ONE bench.py run
-(`python bench.py --steps 3 --warmup 1 --no-cpu-baseline`; FETCH_SIZE and WRITE_SIZE in separate passes). Per kernel the counters
-are sums over all its dispatches in the run = a known number of frames (parity gate + warm-up + timed steps, below); scaled to one
-launch of the configuration's batch. Units KiB; FETCH_SIZE doubled (MI355X_MICROARCH.md: gfx950 tallies 128-byte read requests at
+(`python bench.py --steps 3 --warmup 1 --no-cpu-baseline --gate none --only config3,config4,config5,config5_s2x`; FETCH_SIZE and
+WRITE_SIZE in separate passes). Per kernel the counters are sums over all its dispatches in the run = a known number of frames
+(warm-up + timed steps, no parity-gate launches); scaled to one launch of the configuration's batch. The file records the digest of
+gr-dvbs2rx_amd/csrc it was profiled at (bench.csrc_sha256); bench.py reports `traffic` only for exactly that tree. Units KiB; FETCH_SIZE doubled (MI355X_MICROARCH.md: gfx950 tallies 128-byte read requests at
 64 B; calibrated in round 1 against this kernel family's known message byte count)."""
 import json, os, re, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bench import csrc_sha256
 src = sys.argv[1]
 txt = open(src).read()
 line = [l for l in txt.split("\n") if l.startswith("{")][-1]
@@ -44,11 +47,10 @@ fetch, write = counters("pmc_fetch"), counters("pmc_write")
 steps, warm = bench["steps"], bench["warmup"]
 G = bench["config"]["group_size"]
 runs = {"config2": (bench["roofline"]["kernel"], bench["config"]["frames_per_gpu"], bench["config"]["max_trials"],
-                    G + (warm + steps) * bench["config"]["frames_per_gpu"])}
+                    (warm + steps) * bench["config"]["frames_per_gpu"])}
 for name, c in bench.get("configs", {}).items():
     f = c["frames_per_gpu"]
-    # gate + one untimed call + the timed steps (config3's gate is a whole batch; the others gate on one group)
-    total = (2 + c["steps"]) * f if name == "config3" else G + (1 + c["steps"]) * f
+    total = (1 + c["steps"]) * f  # one untimed call + the timed steps (--gate none: no other launch of the kernel)
     runs[name] = (c["roofline"]["kernel"], f, c["max_trials"], total)
 entries = []
 for name, (kern, frames, trials, total) in runs.items():
@@ -59,4 +61,4 @@ for name, (kern, frames, trials, total) in runs.items():
     entries.append({"config": name, "kernel": kern, "frames_per_launch": frames, "max_trials": trials, "fetch_size_kb_raw_sum": fs,
                     "write_size_kb_sum": ws, "frames_in_sum": total, "hbm_bytes_per_launch": per_launch, "source": "profiles/" + os.path.basename(src)})
     print(f"{name:12s} {kern:40s} {per_launch/1e9:8.2f} GB per launch of {frames} frames")
-json.dump({"note": __doc__.split("\n\n", 1)[1], "entries": entries}, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
+json.dump({"note": __doc__.split("\n\n", 1)[1], "csrc_sha256": csrc_sha256(), "entries": entries}, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)

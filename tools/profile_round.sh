@@ -7,7 +7,7 @@ REPO=$PWD
 OUT=$REPO/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-CMD="python $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline"
+CMD="python $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline --gate none --only config3,config4,config5,config5_s2x"
 cd /tmp
 rocprofv3 --kernel-trace --stats -d $OUT/trace -o t -- $CMD > $OUT/trace.log 2>&1
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU -d $OUT/pmc_sq -o p -- $CMD > $OUT/pmc_sq.log 2>&1
