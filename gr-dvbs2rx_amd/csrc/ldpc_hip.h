@@ -72,7 +72,8 @@ private:
     int out_bits_message_, G_, max_frames_, device_;
     int words_per_check_ = 0; // message dwords per check (4 int8 messages per dword)
     int dmax_ = 0;            // kernel variant: handles check degrees dmax-7 .. dmax (8, 12, ..., 32)
-    uint32_t* d_recs_ = nullptr;  // per-layer records (ldpc_hip.hip)
+    uint32_t* d_recs_ = nullptr;  // per-layer records (ldpc_hip.hip); kRecHeaderWords of header in front of them (d_recs_alloc_)
+    uint32_t* d_recs_alloc_ = nullptr;
     uint32_t* d_wrecs_ = nullptr; // per-(layer, wave) sweep records of the classic kernel
     size_t lds_bytes_ = 0;
     std::string kname_;
@@ -91,6 +92,8 @@ private:
     int* d_iters_ = nullptr;      // per frame: updates done
     int* d_good_ = nullptr;       // per frame: syndrome satisfied at the current state
     int* d_target_ = nullptr;     // per frame: updates to reach in a resume pass
+    int* d_gsync_ = nullptr;      // {arrive, lastbad} per group: group-synchronous stop inside the first pass (ldpc_kernel.hpp, group_decide)
+    bool gsync_on_ = false;
     int* d_flag_ = nullptr;       // [slot] = number of unresolved groups
     int* h_flag_ = nullptr;       // pinned, [slot]
     struct Pending { bool active = false; int n_frames = 0, max_trials = 0, out_mode = 0, frame_base = 0;

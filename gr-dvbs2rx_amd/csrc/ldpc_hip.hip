@@ -56,24 +56,36 @@ __global__ void ldpc_group_targets_kernel(const int* iters, const int* good, int
 
 // Hard decision + MSB-first packing (ldpc_decoder_bb_impl.cc:432-442) and optional soft output
 // (the llr_pdu payload, :422-429), undoing the parity permutation (layered_decoder.hh:155-157).
+// One thread per eight LLRs = one output byte. The information part of the state is in natural order: one 8-byte load, the
+// sign bits gathered with a multiply (bits 7, 15, 23, 31 of a dword -> four adjacent bits), one byte stored (round 2 read
+// byte by byte: 0.49 ms per 4096 normal frames, 1.3 % of a 50-update batch). The parity part (whole-codeword output and the
+// soft output only) is gathered through the permutation pty[360 i + j] = parity[q j + i].
+__device__ __forceinline__ uint32_t neg_bits4(uint32_t w) // offset-binary bytes b0..b3 -> (b0 < 0x80) << 3 | ... | (b3 < 0x80)
+{
+    const uint32_t m = (~w & 0x80808080u) >> 7;            // one bit per byte, at bits 0, 8, 16, 24
+    return ((m * 0x08040201u) >> 24) & 0xfu;               // b0 -> bit 3, b1 -> bit 2, b2 -> bit 1, b3 -> bit 0
+}
 __global__ void ldpc_finalize_kernel(const uint8_t* state, uint8_t* bits, int8_t* llr_out,
                                      int N, int K, int q, int out_bytes)
 {
     const int f = blockIdx.y;
     const uint8_t* s = state + (size_t)f * N;
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= N / 8) return;
-    uint32_t byte = 0;
+    if (b >= N / 8 || (!llr_out && b >= out_bytes)) return;
+    uint2 v;
+    if (8 * b < K) v = *reinterpret_cast<const uint2*>(s + 8 * b); // K % 8 == 0
+    else {
+        uint32_t w[2] = { 0, 0 };
+        int r = 8 * b - K, jq = r / q, iq = r - jq * q;
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
-        const int n = 8 * b + k;
-        int idx = n;
-        if (n >= K) { const int r = n - K; idx = K + kM * (r % q) + r / q; }
-        const uint32_t v = s[idx];
-        if (v < 0x80u) byte |= 1u << (7 - k);
-        if (llr_out) llr_out[(size_t)f * N + n] = (int8_t)(v ^ 0x80u);
+        for (int k = 0; k < 8; k++) {
+            w[k >> 2] |= (uint32_t)s[K + kM * iq + jq] << (8 * (k & 3));
+            if (++iq == q) { iq = 0; ++jq; }
+        }
+        v = make_uint2(w[0], w[1]);
     }
-    if (bits && b < out_bytes) bits[(size_t)f * out_bytes + b] = (uint8_t)byte;
+    if (llr_out) *reinterpret_cast<uint2*>(llr_out + (size_t)f * N + 8 * b) = make_uint2(v.x ^ 0x80808080u, v.y ^ 0x80808080u);
+    if (bits && b < out_bytes) bits[(size_t)f * out_bytes + b] = (uint8_t)((neg_bits4(v.x) << 4) | neg_bits4(v.y));
 }
 
 LdpcDecoderHip::LdpcDecoderHip(const LdpcTableDesc* table, int out_bits_message, int group_size, int max_frames, int device)
@@ -148,7 +160,7 @@ LdpcDecoderHip::LdpcDecoderHip(const LdpcTableDesc* table, int out_bits_message,
         int order[64];
         for (int k = 0; k < L.cnt + 2; k++) order[k] = k;
         uint32_t chain = 0;
-        if (L.block <= lane_chain_max && nc_code == 2 && L.n_conflict == 2 && L.cnt + 2 <= kLaneChainMaxDeg &&
+        if (L.block <= lane_chain_max && nc_code == 2 && L.n_conflict == 2 && (L.cnt + 2 <= kLaneChainMaxDeg || dmax_ >= kLowRegMinDmax) &&
             (sched_.N / 360) * kSvWords >= lane_chain_words(L.block)) {
             const LdpcEntry& a = sched_.entries[L.entry_off], & b = sched_.entries[L.entry_off + 1];
             if (a.base == b.base) {
@@ -197,7 +209,8 @@ LdpcDecoderHip::LdpcDecoderHip(const LdpcTableDesc* table, int out_bits_message,
         hr[(size_t)0 * RS + 4 + 2 * (sched_.layers[0].cnt + 1)] = (uint32_t)sched_.K + 359u;     // previous parity of layer 0: same row, one lane down
         hr[(size_t)0 * RS + 5 + 2 * (sched_.layers[0].cnt + 1)] = 1u;
     }
-    HIP_OK(hipMalloc(&d_recs_, hr.size() * 4));
+    HIP_OK(hipMalloc(&d_recs_alloc_, (hr.size() + kRecHeaderWords) * 4)); // header (group-synchronous stop, filled below) + records
+    d_recs_ = d_recs_alloc_ + kRecHeaderWords;
     HIP_OK(hipMemcpy(d_recs_, hr.data(), hr.size() * 4, hipMemcpyHostToDevice));
     // Short frames whose layers are mostly hazard layers (latency-bound ordered steps) and whose degree rules out the
     // parity-in-records kernel: the 80-VGPR build puts a second workgroup on the CU (measured: short 3/5 and 2/3 +34 %;
@@ -297,6 +310,19 @@ LdpcDecoderHip::LdpcDecoderHip(const LdpcTableDesc* table, int out_bits_message,
     HIP_OK(hipMalloc(&d_iters_, (size_t)max_frames_ * 4));
     HIP_OK(hipMalloc(&d_good_, (size_t)max_frames_ * 4));
     HIP_OK(hipMalloc(&d_target_, (size_t)max_frames_ * 4));
+    // Group-synchronous stop (ldpc_kernel.hpp, group_decide): the frames of a group agree after every syndrome test, so the whole
+    // group stops at the reference's count inside the first pass and the resolution rounds have nothing left to do (they stay as
+    // the fallback; with the rule on, none is enqueued ahead of time). Needs the members of a group resident together: groups of up
+    // to 64 frames (at most 32 pair workgroups of 256 CUs). DVBS2_GROUP_SYNC=0 / 1 overrides (tests run both).
+    gsync_on_ = G_ <= 64;
+    if (const char* e = getenv("DVBS2_GROUP_SYNC")) gsync_on_ = atoi(e) != 0 && G_ <= 64;
+    if (gsync_on_) {
+        HIP_OK(hipMalloc(&d_gsync_, (size_t)(max_frames_ / G_ + 2) * 8));
+        resolve_rounds_ = 0;
+        const unsigned long long a = (unsigned long long)d_iters_, b = (unsigned long long)d_gsync_;
+        const uint32_t hd[kRecHeaderWords] = { (uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32), (uint32_t)G_, 0, 0, 0 };
+        HIP_OK(hipMemcpy(d_recs_alloc_, hd, sizeof(hd), hipMemcpyHostToDevice));
+    }
     if (const char* e = getenv("DVBS2_RESOLVE_ROUNDS")) resolve_rounds_ = std::max(0, std::min(8, atoi(e))); // tests: 0 forces the host-side leftover path
     HIP_OK(hipMalloc(&d_flag_, 4 * kSlots));
     HIP_OK(hipHostMalloc(&h_flag_, 4 * kSlots));
@@ -326,8 +352,8 @@ LdpcDecoderHip::LdpcDecoderHip(const LdpcTableDesc* table, int out_bits_message,
 LdpcDecoderHip::~LdpcDecoderHip()
 {
     DeviceGuard dev_guard(device_);
-    (void)hipFree(d_recs_); (void)hipFree(d_wrecs_); (void)hipFree(d_cu_slots_); (void)hipFree(d_state_); (void)hipFree(d_msgs_);
-    (void)hipFree(d_iters_); (void)hipFree(d_good_); (void)hipFree(d_target_); (void)hipFree(d_flag_);
+    (void)hipFree(d_recs_alloc_); (void)hipFree(d_wrecs_); (void)hipFree(d_cu_slots_); (void)hipFree(d_state_); (void)hipFree(d_msgs_);
+    (void)hipFree(d_iters_); (void)hipFree(d_good_); (void)hipFree(d_target_); (void)hipFree(d_flag_); (void)hipFree(d_gsync_);
     if (h_flag_) (void)hipHostFree(h_flag_);
     if (ev0_) (void)hipEventDestroy(ev0_);
     if (ev1_) (void)hipEventDestroy(ev1_);
@@ -341,7 +367,9 @@ void LdpcDecoderHip::launch_sweep(const int8_t* in, bool resume, int stop_on_goo
     la.recs = d_recs_; la.wrecs = d_wrecs_; la.llr_in = in; la.state = d_state_ + fb * sched_.N;
     la.msgs = d_msgs_ + fb * sched_.q * words_per_check_ * kMsgStride;
     la.iters = d_iters_ + fb; la.good = d_good_ + fb; la.target = resume ? d_target_ + fb : nullptr;
-    la.n_frames = n_frames; la.N = sched_.N; la.K = sched_.K; la.q = sched_.q; la.cap = max_trials; la.stop_on_good = stop_on_good | (soft_bar_ ? 2 : 0);
+    const bool gs = gsync_on_ && !resume && stop_on_good; // group-synchronous stop: bit 2 of the flag word; its words start from zero
+    if (gs) (void)hipMemsetAsync(d_gsync_ + 2 * (size_t)(frame_base / G_), 0, (size_t)((n_frames + G_ - 1) / G_) * 8, stream); // (frame_base is a multiple of the group size: enqueue())
+    la.n_frames = n_frames; la.N = sched_.N; la.K = sched_.K; la.q = sched_.q; la.cap = max_trials; la.stop_on_good = stop_on_good | (soft_bar_ ? 2 : 0) | (gs ? 4 : 0);
     la.tdbg = d_tdbg_; la.lds_bytes = solo_ ? half_lds_bytes(sched_.N) : lds_bytes_; la.stream = stream; la.dense = dense_;
     la.v2 = pr_ ? pr_w1_ : v2_; la.solo = solo_; la.chain = chain_plain_; la.hz2 = hz2_; la.soft = soft_bar_; la.cu_slots = d_cu_slots_;
     la.dm = DemapFused{};
@@ -374,7 +402,8 @@ void LdpcDecoderHip::launch_finalize(const Pending& p)
 {
     if (!p.bits && !p.llr_out) return; // nobody asked for packed bits or LLRs (chain: the BCH stage reads the state)
     const int out_bytes = (p.out_mode ? out_bits_message_ : sched_.N) / 8;
-    hipLaunchKernelGGL(ldpc_finalize_kernel, dim3((sched_.N / 8 + 255) / 256, p.n_frames), dim3(256), 0, p.stream,
+    const int items = p.llr_out ? sched_.N / 8 : out_bytes; // one thread per eight LLRs; without the soft output only the bytes asked for
+    hipLaunchKernelGGL(ldpc_finalize_kernel, dim3((items + 255) / 256, p.n_frames), dim3(256), 0, p.stream,
                        d_state_ + (size_t)p.frame_base * sched_.N, p.bits, p.llr_out, sched_.N, sched_.K, sched_.q, out_bytes);
 }
 
@@ -404,6 +433,16 @@ int LdpcDecoderHip::enqueue(const int8_t* d_llr_in, int n_frames, int max_trials
         if (getenv("DVBS2_TIMING_LAYERS")) { // cycles per layer of frame 0, wave 0 (sum over the sweeps so far)
             std::vector<unsigned long long> hl(sched_.q);
             HIP_RET(hipMemcpy(hl.data(), d_tdbg_ + (size_t)n_frames * 48, hl.size() * 8, hipMemcpyDeviceToHost));
+            {   // hazard-node phases (check_node_hazard, DVBS2_PH): wave 0 = chain heads / walker, wave 5 = body rows
+                std::vector<unsigned long long> hp(32);
+                HIP_RET(hipMemcpy(hp.data(), d_tdbg_ + (size_t)n_frames * 48 + 256, 32 * 8, hipMemcpyDeviceToHost));
+                static const char* const nm[8] = { "P1", "heads", "barrier", "publish+barrier", "walk", "barrier", "steps/finish+barrier", "merge+P3" };
+                for (int w = 0; w < 2; w++) {
+                    fprintf(stderr, "  hazard phases wave %d (cycles/sweep):", w ? 5 : 0);
+                    for (int k = 0; k < 8; k++) fprintf(stderr, " %s %.0f", nm[k], (double)hp[16 * w + k] / std::max(1, max_trials));
+                    fprintf(stderr, "\n");
+                }
+            }
             HIP_RET(hipMemset(d_tdbg_ + (size_t)n_frames * 48, 0, 512 * 8));
             for (int i = 0; i < sched_.q; i++) fprintf(stderr, "  layer %3d block %3d nconf %d deg %2d: %8.0f cycles/sweep\n", i, sched_.layers[i].block, sched_.layers[i].n_conflict, sched_.layers[i].cnt + 2, (double)hl[i] / std::max(1, max_trials));
         }

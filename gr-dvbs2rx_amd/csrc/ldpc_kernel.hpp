@@ -27,6 +27,12 @@ constexpr int kSvWords = 14;        // sign-vector dwords per 360-bit group (360
 // 360*g + (j + rot) mod 360 = (j < thr ? S0 + j : S0 + j - 360).
 __host__ __device__ constexpr int rec_stride(int dmax) { return 2 * dmax + 4; }       // per-layer records (recs)
 __host__ __device__ constexpr int rec_stride_wave(int dmax) { return 2 * dmax + 12; } // per-(layer, wave) records of the packed builds (wrecs)
+// In FRONT of the per-layer records (recs[-kRecHeaderWords ..]): what the group-synchronous stop needs (group_decide) -- the base of the
+// handle's `iters` array (the kernel's own `iters` argument minus it = the first frame of this launch), the base of the per-group words
+// and the group size. Kept out of the kernel's argument list on purpose: arguments stay live in SGPRs for the whole kernel, and the
+// one-frame builds of the degree class 16 answered three more of them with 25 more spilled scalars and 2-3 % (measured); here they are
+// fetched with two scalar loads once per update, by the lane that reports.
+constexpr int kRecHeaderWords = 8; // [0,1] iters base, [2,3] group words base, [4] group size, rest unused
 // per frame: N LLR bytes, then the sign-vector area (syndrome test; scratch of the ordered hazard phases during a sweep:
 // at least kChainScratchWords dwords, which is what short frames get instead of their small sign-vector area), then 8 flag words
 constexpr int kChainMaxBlock = 128;                                             // largest block walked as a register chain
@@ -52,6 +58,52 @@ __device__ __forceinline__ void frame_barrier(volatile int* ctr, int& epoch, int
     asm volatile("" ::: "memory");
 }
 #define lds_barrier() frame_barrier(hb_ctr, hb_epoch, hb_lane)
+// The same where only LDS (the flag words) is handed over: without the wait for outstanding vector memory operations that
+// __syncthreads() implies -- the group report of group_decide() is two fire-and-forget atomics whose acknowledgement would
+// otherwise be waited for at the next barrier (short frames: 1.4 % of a sweep, measured).
+__device__ __forceinline__ void frame_barrier_lds(volatile int* ctr, int& epoch, int lane)
+{
+    if (ctr) { frame_barrier(ctr, epoch, lane); return; }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+#define lds_only_barrier() frame_barrier_lds(hb_ctr, hb_epoch, hb_lane)
+
+// Group-synchronous stopping rule. The reference decodes a SIMD batch of G frames in lockstep and stops the whole batch at the
+// first update count at which EVERY lane passes the syndrome test (while (bad(any lane) && --trials >= 0),
+// layered_decoder.hh:153). Frames of one group are dispatched together (consecutive workgroups) and run the same instruction
+// stream, so they can simply agree after every test: per group two words in global memory,
+//   arrive   += 1 per member and test;          lastbad = max(update count + 1) over the members that failed a test.
+// A member that FAILS its test at count `it` knows the group goes on and does not wait. A member that PASSES waits until all
+// `members` have reported for `it` and stops iff nobody failed there -- then every member stops at the same count, which is
+// the reference's result, and no resume pass is needed. Returns 1 = stop (group good), 0 = one more update, 2 = gave up waiting
+// (members not co-resident for milliseconds: never observed; the frame then stops at its own good point like in round 1/2 and
+// the host-side resolution, ldpc_group_targets_kernel + resume launches, finishes the group -- a frame only ever advances past
+// a count at which some member is known to have failed, so it can never overshoot the reference's count).
+constexpr int kGroupSpinMax = 1 << 12; // polls of ~2 us
+// All atomics are RELAXED at agent scope: a release / acquire at agent scope writes back and invalidates the (per-XCD) L2, which
+// at one report per frame and update cost the never-converging batch 12 % (measured). No ordering with other memory is needed --
+// only the two words themselves carry information, both live in one 8-byte slot (one cache line, one coherence point, and a
+// member's two updates are issued in order by one lane), and the reader fetches `lastbad` with an atomic read-modify-write after
+// it has seen the arrival count, so it observes every `lastbad` update of the members it counted.
+__device__ __forceinline__ int group_decide(int* gw /*{arrive, lastbad} of this frame's group*/, int members, int it, bool good)
+{
+    if (!good) {
+        __hip_atomic_fetch_max(gw + 1, it + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(gw, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return 0; // (nothing is waited for: both are fire-and-forget)
+    }
+    __hip_atomic_fetch_add(gw, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int want = members * (it + 1);
+    for (int spin = 0;; spin++) {
+        // a member that already failed at this count settles it without waiting for the rest (the slow frames run ahead: a
+        // failing pre-test skips the full test)
+        if (__hip_atomic_fetch_max(gw + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > it) return 0;
+        if (__hip_atomic_load(gw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) break;
+        if (spin > kGroupSpinMax) return 2;
+        __builtin_amdgcn_s_sleep(8);
+    }
+    return __hip_atomic_fetch_max(gw + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= it ? 1 : 0;
+}
 
 // Pinned instruction selection for the two spots where the compiler's canonical form costs more issue slots.
 // clamp(a + b + 128, 0, 255) as v_add3_u32 + v_med3_i32 (the compiler emits add, max, add, min).
@@ -217,6 +269,72 @@ __device__ __forceinline__ void check_node(uint8_t* __restrict__ lds /*the whole
         const uint32_t w1 = ((DEG + 3) / 4 > 1) ? nm[1] : 0x80808080u;
         nm[1] = (w1 & 0x00ffffffu) | ((uint32_t)spare << 24);
     }
+}
+
+// Low-register form of check_node for the high degree classes (LOWREG builds, DMAX >= kLowRegMinDmax). The plain node keeps
+// address, input and raw magnitude of every edge from its first phase to its last: 3 x 30 registers for degree 30 on top of
+// 24 message registers do not fit the 168 a wave has with three waves per SIMD, and the difference goes through scratch
+// (round 2: 52 spilled VGPRs, 1.5-1.6 x the algorithmic traffic). Here an edge keeps ONE register between the phases,
+//   pm = |Lb - mb| << 8 | (inp & 0xff)        (|Lb - mb| = raw magnitude + 1 in 0 .. 255, inp = sat8(L - m))
+// and its address is computed again in the output phase (four full-rate instructions). The two smallest are taken over
+// the pm words themselves (ordered by magnitude first); "mag == min0 ? min1 : min0" becomes "pm == smallest pm": if another
+// edge has the same magnitude then min1 == min0 and either choice gives the same value.
+constexpr int kLowRegMinDmax =
+#ifdef DVBS2_LOWREG_MIN_DMAX
+    DVBS2_LOWREG_MIN_DMAX; // experiments
+#else
+    1000; // OFF. Measured on MI355X in round 3 (interleaved A/B against the plain nodes, notes/r03_experiments.md): the form removes every
+          // spilled VGPR of the degree class 32 (52 -> 0) -- and S2X 154/180 LOSES 12 %, 9/10 normal 4-6 %, the classes 20 .. 28 5-12 %:
+          // the class is bound by VALU issue, not by its scratch traffic, and the form costs ~18 % more VALU work per edge
+#endif
+template <int DMAX, bool HZ2> constexpr bool kLowReg = DMAX >= kLowRegMinDmax;
+__device__ __forceinline__ int pm_pack(int magp, int d) { return (int)__builtin_amdgcn_perm((uint32_t)magp, (uint32_t)d, 0x0c0c0400u); } // d.b0 | magp.b0 << 8
+__device__ __forceinline__ int pm_inp(int pm) { return __builtin_amdgcn_sbfe(pm, 0, 8); }
+__device__ __forceinline__ int pm_min_clamped(int p) { return clamp_mag((int)((uint32_t)p >> 8) - 1); } // R2 on a minimum: clamp(|x| - 1, 0, 126)
+template <int DEG, bool LAYER0>
+__device__ __forceinline__ void check_node_lr(const uint32_t* ent, int jj, int lb, const uint32_t* mw, uint32_t* nm)
+{
+    __builtin_amdgcn_s_setprio(0);
+    const int jjb = jj + lb, jjb360 = jjb - kM;
+    auto addr = [&](int k) -> int {
+        if (k >= DEG - 2 && !(LAYER0 && k == DEG - 1)) return jjb + (int)ent[2 * k];
+        return wrap_addr(jj, jjb, jjb360, ent[2 * k], ent[2 * k + 1]);
+    };
+    const bool last_valid = !LAYER0 || jj != 0;
+    int pm[DEG];
+    int signs = 0;
+#pragma unroll
+    for (int k = 0; k < DEG; k++) {
+        const int Lb = lds_rd(addr(k));
+        const int mb = (int)((mw[k >> 2] >> (8 * (k & 3))) & 0xffu);
+        int d = min(max(Lb - mb, -128), 127);
+        const int magp = (int)__builtin_amdgcn_sad_u16((uint32_t)Lb, (uint32_t)mb, 0u);
+        if (LAYER0 && k == DEG - 1) { d = last_valid ? d : 0; pm[k] = last_valid ? pm_pack(magp, d) : (kMagAbsent << 8); }
+        else pm[k] = pm_pack(magp, d);
+        signs ^= d;
+    }
+    __builtin_amdgcn_s_setprio(1);
+    int p0, p1;
+    two_smallest<DEG>(pm, p0, p1);
+    const int min0 = pm_min_clamped(p0), min1 = pm_min_clamped(p1);
+#pragma unroll
+    for (int w = 0; w < (DEG + 3) / 4; w++) nm[w] = 0;
+    int msgc[4];
+#pragma unroll
+    for (int k = 0; k < DEG; k++) {
+        const int other = pm[k] == p0 ? min1 : min0;
+        const int inp = pm_inp(pm[k]);
+        const int sg = (signs ^ inp) >> 31;
+        const int out = (other ^ sg) - sg;
+        const int nl = sat_sum_u8(inp, out);
+        if (!(LAYER0 && k == DEG - 1) || last_valid) lds_wr(addr(k), nl);
+        msgc[k & 3] = min(max(out, -32), 31);
+        if ((k & 3) == 3 || k == DEG - 1) {
+            if ((k & 3) < 3) { msgc[3] = 0; if ((k & 3) < 2) { msgc[2] = 0; if ((k & 3) < 1) msgc[1] = 0; } }
+            nm[k >> 2] = pack4_lo8(msgc[0], msgc[1], msgc[2], msgc[3]) ^ 0x80808080u;
+        }
+    }
+    __builtin_amdgcn_s_setprio(3);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
@@ -548,20 +666,50 @@ constexpr int kMaxHazard = 8;     // ordered entries per check in the common bui
 constexpr int kMaxHazardHz2 = 12;
 constexpr int kMaxHazard12Dmax = 28; // (the degree class 32 has the two-level walk only: twelve ordered entries on top of 30 edges do not fit its registers)
 constexpr int kHazardWalk = 15; // header code: too many hazard entries, fall back to the single-wave chunk walk
-template <int DEG, int NC, bool LAYER0, bool PR = false, bool LAST = false, bool TWO = false /*two-level walk compiled in*/>
+template <int DEG, int NC, bool LAYER0, bool PR = false, bool LAST = false, bool TWO = false /*two-level walk compiled in*/,
+          bool LR = false /*low-register form (see check_node_lr): regular entries keep one packed word, their addresses are computed twice*/>
 __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, const uint32_t* ent, int jj, int lb, bool work,
                                                   int block, int block2 /*two-level walk: rows per outer block, 0 = off*/, const uint32_t* mw, uint32_t* nm, int own_in, int* carry,
                                                   uint32_t* tab /*lane_chain_words(block) of LDS scratch when the layer is a lane chain*/,
-                                                  volatile int* hb_ctr, int& hb_epoch, const int hb_lane /*frame barrier state*/)
+                                                  volatile int* hb_ctr, int& hb_epoch, const int hb_lane /*frame barrier state*/,
+                                                  unsigned long long* ph = nullptr /*timing builds: cycles per phase of this node (8 slots), else null*/)
 {
+    unsigned long long tph = ph ? __builtin_readcyclecounter() : 0ull;
+#define DVBS2_PH(i) do { if (ph) { const unsigned long long t_ = __builtin_readcyclecounter(); ph[i] += t_ - tph; tph = t_; } } while (0)
     constexpr bool OWN_REG = PR && !LAST;     // entry DEG-2 (see check_node)
     constexpr bool PREV_REG = PR && !LAYER0;  // entry DEG-1
-    int ad[DEG], inp[DEG], mg[DEG];
+    static_assert(!(LR && PR), "the low-register form is for the classic layout");
+    constexpr int NAD = LR ? NC : DEG; // LR: only the ordered entries keep their addresses
+    int ad[NAD], inp[LR ? NC : DEG], mg[LR ? NC : DEG];
+    int pm[LR ? DEG : 1];  // LR: regular entry k keeps pm[k] (check_node_lr)
+    int p0 = 0, p1 = 0;
     const int jjb = jj + lb, jjb360 = jjb - kM;
     int min0 = 127, min1 = 127, signs = 0;
     int spare = 0x80;
     const bool last_valid = !LAYER0 || jj != 0;
+    auto addr = [&](int k) -> int {
+        if (k >= DEG - 2 && !(LAYER0 && k == DEG - 1)) return jjb + (int)ent[2 * k];
+        return wrap_addr(jj, jjb, jjb360, ent[2 * k], ent[2 * k + 1]);
+    };
     __builtin_amdgcn_s_setprio(0); // as in check_node; the ordered steps below run at the top priority
+    if constexpr (LR) {
+        if (work) {
+#pragma unroll
+            for (int k = 0; k < NC; k++) ad[k] = addr(k);
+#pragma unroll
+            for (int k = NC; k < DEG; k++) {
+                const int Lb = lds_rd(addr(k));
+                const int mb = (int)((mw[k >> 2] >> (8 * (k & 3))) & 0xffu);
+                int d = min(max(Lb - mb, -128), 127);
+                const int magp = (int)__builtin_amdgcn_sad_u16((uint32_t)Lb, (uint32_t)mb, 0u);
+                if (LAYER0 && k == DEG - 1) { d = last_valid ? d : 0; pm[k] = last_valid ? pm_pack(magp, d) : (kMagAbsent << 8); }
+                else pm[k] = pm_pack(magp, d);
+                signs ^= d;
+            }
+            two_smallest<DEG - NC>(pm + NC, p0, p1);
+            min0 = pm_min_clamped(p0); min1 = pm_min_clamped(p1);
+        }
+    } else
     if (work) {
 #pragma unroll
         for (int k = 0; k < DEG; k++) {
@@ -583,6 +731,7 @@ __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, con
         two_smallest<DEG - NC>(mg + NC, min0, min1); // raw magnitudes of the regular entries (see mag_raw)
         min0 = clamp_mag(min0); min1 = clamp_mag(min1);
     }
+    DVBS2_PH(0); // P1: regular entries read and reduced
 #pragma unroll
     for (int w = 0; w < (DEG + 3) / 4; w++) nm[w] = 0;
     // P2 keeps only what the NEXT block needs on its critical path: the new hazard LLRs. For hazard entry k the
@@ -598,28 +747,47 @@ __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, con
     // incrementally (one subtract + one unsigned compare select the rows of the block).
     __builtin_amdgcn_s_setprio(3);
     bool lane_chain = false;
-    if constexpr (NC == 2 && DEG <= kLaneChainMaxDeg && !PR) lane_chain = tab != nullptr; // wave-uniform (header bit 12)
-    if constexpr (NC == 2 && DEG <= kLaneChainMaxDeg && !PR) if (lane_chain) {
-        // LANE CHAIN (one hazard pair, block <= 64, host-ordered so that entry 0's bit of row r is entry 1's bit of
-        // row r + block). A lone wave issues one instruction per ~6.7 cycles whatever it is, so an ordered step costs
+    // (the low-register form has room for it at every degree)
+    constexpr bool kLaneChainBuilt = NC == 2 && (LR || DEG <= kLaneChainMaxDeg) && !PR;
+    if constexpr (kLaneChainBuilt) lane_chain = tab != nullptr; // wave-uniform (header bit 12)
+    if constexpr (kLaneChainBuilt) if (lane_chain) {
+        // LANE CHAIN (one hazard pair, block <= 128, host-ordered so that entry 0's bit of row r is entry 1's bit of
+        // row r + block). A lone wave issues one instruction per 4-7 cycles whatever it is, so an ordered step costs
         // its instruction count: the recurrence r -> r + block is walked by the `block` lanes that own rows
         // 0..block-1 with the chained LLR in a register, ~20 instructions per step, no exec-mask bookkeeping, no LDS
-        // hand-over, no barrier per step; everything else happens before and after, in parallel over all rows:
-        //   A  rows < block (chain heads, nothing precedes them): full two-entry step; entry-1 LLR written at once
-        //      (rows >= 360 - block read it as their entry-0 LLR)                                        | barrier
-        //   B  rows >= block: read entry 0 (no earlier row of this layer writes it), publish
-        //      {inp0, partial min0, partial sign, message byte 1}                                        | barrier
+        // hand-over, no barrier per step; everything else happens before and after, in parallel over all rows. Round 3: two
+        // barriers per layer instead of four (cycle stamps, DVBS2_PH: the heads' step, the publishing pass and their barriers
+        // cost a chain layer of table B4 ~1.4 k of its ~5 k cycles):
+        //   A  together with the first phase (no barrier in between): rows < 360 - block read entry 0 -- no earlier row of
+        //      this layer writes that bit -- ; the heads (rows < block, nothing precedes them) do their full two-entry step and
+        //      write entry 1 at once (the only reader of that bit is the tail row r + 360 - block, after the walk); the other
+        //      rows publish {inp0, partial min0, partial sign, message byte 1}                             | barrier
         //   C  chain lanes: incoming entry-1 LLR -> new entry-0 LLR of row r, incoming value logged      | barrier
-        //   D  rows >= block: complete both outputs from the logged value; write entry 1; the last row of a chain
-        //      also writes entry 0 (in the reference's order it is the final writer of that bit).
+        //   D  rows >= block: (tails first read entry 0 = what their head wrote in A) complete both outputs from the
+        //      logged value; write entry 1; the last row of a chain also writes entry 0 (in the reference's order it is the
+        //      final writer of that bit). No barrier towards the outputs of the regular entries: other bits.
+        // (The walk on exact small integers in float -- six instructions per step as in the packed chain node instead of ~20 -- was
+        // measured here too in round 3: the 16-byte operand records and the float state cost every build of every degree class 4-6
+        // VGPRs; B4 113.2 k -> 112.4 k, the 80-VGPR and one-frame builds -4 ... -8 %. It stays in the packed chain node.)
         uint8_t* ulog = reinterpret_cast<uint8_t*>(tab + kM + block); // after the per-row records (360 rows + one block of padding)
         int chained = 0x80;
+        auto publish = [&]() {
+            tab[jj] = ((uint32_t)inp[0] & 0x1ffu) | ((uint32_t)min0 << 9) | (((uint32_t)signs >> 31) << 16) | ((uint32_t)hmb[1] << 24);
+        };
         const bool head = work && jj < block, body = work && jj >= block;
-        if (head) {
-            const int L0 = lds_rd(ad[0]), L1 = lds_rd(ad[1]);
+        // (degrees above 20 without the low-register form keep the round-2 order -- heads | barrier | publishing | barrier | walk |
+        // barrier | completion | barrier --: reading entry 0 inside the first phase costs the degree class 28 sixteen more spilled
+        // registers and table B10 7 %)
+        constexpr bool kTwoBarrier = LR || DEG <= 20;
+        const bool orig0 = work && (kTwoBarrier ? jj + block < kM : jj < block); // entry 0 still holds its value from before the layer (every head is one: block <= 128)
+        if (orig0) {
+            const int L0 = lds_rd(ad[0]);
             inp[0] = min(max(L0 - hmb[0], -128), 127);
-            inp[1] = min(max(L1 - hmb[1], -128), 127);
             mg[0] = mag_raw(L0, hmb[0]);
+        }
+        if (head) {
+            const int L1 = lds_rd(ad[1]);
+            inp[1] = min(max(L1 - hmb[1], -128), 127);
             mg[1] = mag_raw(L1, hmb[1]);
             int o0, o1;
             asm("v_med3_i32 %0, %1, 0, %2" : "=v"(o0) : "v"(mg[1]), "v"(min0));
@@ -629,17 +797,23 @@ __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, con
             hout[1] = (o1 ^ s1) - s1;
             chained = sat_sum_u8(inp[0], hout[0]);
             lds_wr(ad[1], sat_sum_u8(inp[1], hout[1]));
+        } else if (kTwoBarrier && orig0)
+            publish();
+        if constexpr (!kTwoBarrier) {
+            lds_barrier();
+            if (body) { // every row below the heads, tails included (their entry 0 is what a head just wrote)
+                const int L0 = lds_rd(ad[0]);
+                inp[0] = min(max(L0 - hmb[0], -128), 127);
+                mg[0] = mag_raw(L0, hmb[0]);
+                publish();
+            }
         }
+        DVBS2_PH(1); // chain heads + publishing
         lds_barrier();
-        if (body) {
-            const int L0 = lds_rd(ad[0]);
-            inp[0] = min(max(L0 - hmb[0], -128), 127);
-            mg[0] = mag_raw(L0, hmb[0]);
-            tab[jj] = ((uint32_t)inp[0] & 0x1ffu) | ((uint32_t)min0 << 9) | (((uint32_t)signs >> 31) << 16) | ((uint32_t)hmb[1] << 24);
-        }
-        lds_barrier();
+        DVBS2_PH(3); // barrier
         if (head) {
-            // rows past 359 read the padding of the table and log into the padding: no per-lane predicate in the loop
+            // rows past 359 read the padding of the table and log into the padding: no per-lane predicate in the loop; the record
+            // of a tail row (last of its chain) is not written: what is computed from it is never used
             const uint32_t* tp = tab + jj + block;
             uint8_t* up = ulog + jj + block;
             uint32_t t = *tp;
@@ -658,8 +832,15 @@ __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, con
                 chained = sat_sum_u8(i0, (o0 ^ s0) - s0);
             }
         }
+        DVBS2_PH(4); // walk
         lds_barrier();
+        DVBS2_PH(5); // barrier after the walk
         if (body) {
+            if (kTwoBarrier && !orig0) { // tail: entry 0 = the entry-1 value its head wrote before the walk
+                const int L0 = lds_rd(ad[0]);
+                inp[0] = min(max(L0 - hmb[0], -128), 127);
+                mg[0] = mag_raw(L0, hmb[0]);
+            }
             const int L1 = ulog[jj];
             inp[1] = min(max(L1 - hmb[1], -128), 127);
             mg[1] = mag_raw(L1, hmb[1]);
@@ -789,7 +970,8 @@ __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, con
         // same wavefront (LDS operations of a wave execute in program order)
         if ((start >> 6) != ((start + 2 * block - 1) >> 6)) lds_barrier();
     }
-    lds_barrier();
+    if (!lane_chain || !(LR || DEG <= 20)) lds_barrier(); // (uniform; the last phase of a two-barrier lane chain and the outputs below touch different bits)
+    DVBS2_PH(6); // ordered steps of the block scheme + closing barrier / completion of the chain rows
     if constexpr (NC == 2) { mg[0] = clamp_mag(mg[0]); mg[1] = clamp_mag(mg[1]); } // raw in the loop (127 where no step ran: idle rows)
 #pragma unroll
     for (int k = 0; k < NC; k++) {
@@ -799,6 +981,30 @@ __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, con
         nm[k >> 2] |= (uint32_t)(min(max(hout[k], -32), 31) + 128) << (8 * (k & 3));
     }
     const int s01 = min0 + min1;
+    if constexpr (LR) {
+        // The regular entries only know the two smallest of THEMSELVES (p0, p1); after the ordered entries were merged a regular
+        // entry's "minimum of the others" is: the entry that holds p0 takes min(second regular minimum, smallest ordered magnitude),
+        // every other one min(first regular minimum, smallest ordered magnitude) -- i.e. min1 for the holder of the overall
+        // minimum and min0 otherwise, decided on the merged (min0, min1) like this:
+        //   hmin = smallest ordered magnitude (clamped); r0, r1 = the regular minima (clamped)
+        //   holder of p0:  min(r1, hmin);   others:  min(r0, hmin)
+        if (work) {
+            int hmin = 127;
+#pragma unroll
+            for (int k = 0; k < NC; k++) hmin = min(hmin, mg[k]);
+            const int o_first = min(pm_min_clamped(p1), hmin), o_rest = min(pm_min_clamped(p0), hmin);
+#pragma unroll
+            for (int k = NC; k < DEG; k++) {
+                const int other = pm[k] == p0 ? o_first : o_rest;
+                const int ip = pm_inp(pm[k]);
+                const int sg = (signs ^ ip) >> 31;
+                const int out = (other ^ sg) - sg;
+                const int nl = sat_sum_u8(ip, out);
+                if (!(LAYER0 && k == DEG - 1) || last_valid) lds_wr(addr(k), nl);
+                nm[k >> 2] |= (uint32_t)(min(max(out, -32), 31) + 128) << (8 * (k & 3));
+            }
+        }
+    } else
     if (work) {
 #pragma unroll
         for (int k = 0; k < DEG; k++) {
@@ -815,11 +1021,14 @@ __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, con
         }
         if (PR) nm[1] = (nm[1] & 0x00ffffffu) | ((uint32_t)spare << 24);
     }
+    DVBS2_PH(7); // merge + outputs of the regular entries
+#undef DVBS2_PH
 }
 
 // degrees DMAX-7 .. DMAX are instantiated for kernel variant DMAX
 #define DVBS2_DEG_CASE(D) case D: if constexpr (D >= 3 && D <= DMAX && D > DMAX - 8) { \
-        if (layer0) check_node<(D >= 3 ? D : 3), true>(lds_all, ent, jj, lb, mw, nm); else check_node<(D >= 3 ? D : 3), false>(lds_all, ent, jj, lb, mw, nm); } break;
+        if constexpr (kLowReg<DMAX, HZ2>) { if (layer0) check_node_lr<(D >= 3 ? D : 3), true>(ent, jj, lb, mw, nm); else check_node_lr<(D >= 3 ? D : 3), false>(ent, jj, lb, mw, nm); } \
+        else { if (layer0) check_node<(D >= 3 ? D : 3), true>(lds_all, ent, jj, lb, mw, nm); else check_node<(D >= 3 ? D : 3), false>(lds_all, ent, jj, lb, mw, nm); } } break;
 #define DVBS2_DEG_SWITCH switch (deg) { \
         DVBS2_DEG_CASE(3) DVBS2_DEG_CASE(4) DVBS2_DEG_CASE(5) DVBS2_DEG_CASE(6) DVBS2_DEG_CASE(7) DVBS2_DEG_CASE(8) \
         DVBS2_DEG_CASE(9) DVBS2_DEG_CASE(10) DVBS2_DEG_CASE(11) DVBS2_DEG_CASE(12) DVBS2_DEG_CASE(13) DVBS2_DEG_CASE(14) \
@@ -847,7 +1056,7 @@ __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, con
         default: break; }
 
 #define DVBS2_HAZ_CALL(D, NCV) { if constexpr (D - 2 >= NCV) { \
-        if (layer0) check_node_hazard<D, NCV, true, false, false, HZ2>(lds_all, ent, jj, lb, work, block, block2, mw, nm, 0, nullptr, htab, hb_ctr, hb_epoch, hb_lane); else check_node_hazard<D, NCV, false, false, false, HZ2>(lds_all, ent, jj, lb, work, block, block2, mw, nm, 0, nullptr, htab, hb_ctr, hb_epoch, hb_lane); } }
+        if (layer0) check_node_hazard<D, NCV, true, false, false, HZ2, kLowReg<DMAX, HZ2>>(lds_all, ent, jj, lb, work, block, block2, mw, nm, 0, nullptr, htab, hb_ctr, hb_epoch, hb_lane, hz_ph); else check_node_hazard<D, NCV, false, false, false, HZ2, kLowReg<DMAX, HZ2>>(lds_all, ent, jj, lb, work, block, block2, mw, nm, 0, nullptr, htab, hb_ctr, hb_epoch, hb_lane, hz_ph); } }
 #define DVBS2_HAZ_CASE(D) case D: if constexpr (D >= 4 && D <= DMAX && D > DMAX - 8) { \
         if (nc == 2) DVBS2_HAZ_CALL((D >= 4 ? D : 4), 2) else if (nc == 4) DVBS2_HAZ_CALL((D >= 4 ? D : 4), 4) else { if constexpr (HZ2 && DMAX <= kMaxHazard12Dmax) { if (nc == 8) DVBS2_HAZ_CALL((D >= 4 ? D : 4), 8) else DVBS2_HAZ_CALL((D >= 4 ? D : 4), 12) } else DVBS2_HAZ_CALL((D >= 4 ? D : 4), 8) } } break;
 #define DVBS2_HAZ_SWITCH switch (deg) { \
@@ -889,7 +1098,8 @@ __global__ __launch_bounds__(SOLO ? kSoloThreads : kThreads, SOLO ? 4 : MINW) vo
     const uint32_t* __restrict__ recs, const uint32_t* __restrict__ wrecs /*per (layer, wave) sweep records*/,
     const int8_t* __restrict__ llr_in, uint8_t* __restrict__ state,
     uint32_t* __restrict__ msgs, int* __restrict__ iters, int* __restrict__ good, const int* __restrict__ target,
-    int n_frames, int N, int K, int q, int cap, int stop_on_good, unsigned long long* __restrict__ tdbg, int* __restrict__ cu_slots,
+    int n_frames, int N, int K, int q, int cap, int stop_on_good /*bit 0: stop at a good syndrome, bit 1: software frame barriers, bit 2: group-synchronous stop*/,
+    unsigned long long* __restrict__ tdbg, int* __restrict__ cu_slots,
     const DemapFused dm /*mode != 0: a fresh decode takes XFECFRAME symbols and demaps while loading (llr_in is null then)*/)
 {
     unsigned long long tm_bar = 0, tm_body = 0, tm_conf = 0, tm_synd = 0, tm_sweep = 0, tm_load = 0, tm_s1 = 0;
@@ -1158,10 +1368,23 @@ __global__ __launch_bounds__(SOLO ? kSoloThreads : kThreads, SOLO ? 4 : MINW) vo
         lds_barrier();
         } // full_any
         if (need_synd) is_good = need_full && flags[0] == 0;
-        if (!finished && (it >= tgt || ((stop_on_good & 1) && is_good))) finished = true;
+        const bool gs = (stop_on_good & 5) == 5; // group-synchronous stop (group_decide), first pass only
+        if (!finished && (it >= tgt || (!gs && (stop_on_good & 1) && is_good))) finished = true;
         lds_barrier(); // everyone has read flags[0]
-        if (tid == 0) { flags[0] = 0; flags[2] = 0; flags[1] = finished ? 1 : 0; }
-        lds_barrier();
+        if (tid == 0) {
+            int fin = finished ? 1 : 0;
+            if (gs && !finished) {
+                const uint32_t* hd = recs - kRecHeaderWords; // (uniform: scalar loads)
+                const int* iters0 = reinterpret_cast<const int*>(((unsigned long long)hd[1] << 32) | hd[0]);
+                int* gwords = reinterpret_cast<int*>(((unsigned long long)hd[3] << 32) | hd[2]);
+                const int G = (int)hd[4];
+                const int g = f / G; // within this launch (its first frame is a multiple of the group size)
+                fin = group_decide(gwords + 2 * ((int)(iters - iters0) / G + g), min(G, n_frames - g * G), it, is_good) != 0;
+            }
+            flags[0] = 0; flags[2] = 0; flags[1] = fin;
+        }
+        lds_only_barrier();
+        if (gs) finished = flags[1] != 0; // (uniform over the frame)
         TSTAMP(tS1); tm_synd += tS1 - tS0;
         if (finished && (soft_bar || SOLO || other_flags[1])) break; // uniform over the barrier domain
 
@@ -1172,6 +1395,8 @@ __global__ __launch_bounds__(SOLO ? kSoloThreads : kThreads, SOLO ? 4 : MINW) vo
         const int row = tid < kM ? tid : kM - 1;
         const int row4 = row * 4;
         const bool zero_msgs = it == 0; // uniform over the half
+        // timing builds: cycles per phase of the hazard nodes, frame 0, lane 0 of waves 0 and 5 (slots 256.. and 272.. after the per-layer sums)
+        unsigned long long* const hz_ph = (TIMING && tdbg && f == 0 && (tid == 0 || tid == 320)) ? tdbg + (size_t)n_frames * 48 + 256 + (tid ? 16 : 0) : nullptr;
         uint32_t pre[MW]; // messages of the next layer for check tid, loaded one layer ahead
         if (work) {
 #pragma unroll
@@ -1230,7 +1455,11 @@ __global__ __launch_bounds__(SOLO ? kSoloThreads : kThreads, SOLO ? 4 : MINW) vo
                 TSTAMP(tC); tm_body += tC - tB;
                 if (TIMING && tdbg && f == 0 && tid == 0) tdbg[(size_t)n_frames * 48 + i] += tC - tA; // per-layer cycles of frame 0, wave 0 (incl. its barrier)
             } else {
+#ifdef DVBS2_EXP_NOHAZ // register-pressure experiments: the regular path alone
+                if (false) {
+#else
                 if (nc != kHazardWalk) {
+#endif
                     // sequential-order hazard inside the layer: check_node_hazard (every thread takes every barrier)
                     const int jj = row;
                     // hv2: packed single-pair chain (check_node_chain_v2): two's complement messages. In a build without the packed regular
@@ -1315,7 +1544,11 @@ struct LdpcLaunch {
 };
 template <int DMAX> hipError_t ldpc_variant_prepare(size_t pair_lds_bytes, size_t solo_lds_bytes);
 template <int DMAX> void ldpc_variant_launch(const LdpcLaunch& a);
+#ifdef DVBS2_SOLO_MAX_DMAX
+template <int DMAX> constexpr bool kSoloBuilt = (DMAX <= DVBS2_SOLO_MAX_DMAX); // experiments: one-frame workgroups for the low-register builds
+#else
 template <int DMAX> constexpr bool kSoloBuilt = (DMAX <= 16);
+#endif
 // plain builds with the packed chain node: measured SLOWER than the plain build's own lane chain (B4 107.8 k vs 109.8 k, B5 57.9 k vs
 // 62.2 k frames/s) although its ordered steps cost a third -- the node's register state hurts the rest of the kernel. Not built.
 template <int DMAX> constexpr bool kHz2Built = (DMAX >= 12);

@@ -118,7 +118,7 @@ template <bool W1>
 __global__ __launch_bounds__(kThreads, 6) void ldpc_layered_pr_kernel(
     const uint32_t* __restrict__ recs, const int8_t* __restrict__ llr_in, uint8_t* __restrict__ state,
     uint32_t* __restrict__ msgs, int* __restrict__ iters, int* __restrict__ good, const int* __restrict__ target,
-    int n_frames, int N, int K, int q, int cap, int stop_on_good)
+    int n_frames, int N, int K, int q, int cap, int stop_on_good /*bit 0: stop at a good syndrome, bit 2: group-synchronous stop (ldpc_kernel.hpp, group_decide)*/)
 {
     if (!llr_in) { // resume launch: a workgroup whose frames are both at their target leaves before touching LDS
         const int fa = 2 * (int)blockIdx.x, fb = fa + 1;
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(kThreads, 6) void ldpc_layered_pr_kernel(
     bool is_good = false;
     for (;;) {
         // ---- syndrome test: pre-test on one layer, full test only for frames that pass it (see ldpc_kernel.hpp) ----
-        const bool need_synd = !finished && (stop_on_good || it >= tgt);
+        const bool need_synd = !finished && ((stop_on_good & 1) || it >= tgt);
         if (need_synd && active) {
             const int i0 = it % q;
             const uint32_t* rec = recs + (size_t)i0 * RS;
@@ -275,10 +275,23 @@ __global__ __launch_bounds__(kThreads, 6) void ldpc_layered_pr_kernel(
             }
         }
         if (need_synd) is_good = need_full && flags[0] == 0;
-        if (!finished && (it >= tgt || (stop_on_good && is_good))) finished = true;
+        const bool gs = (stop_on_good & 5) == 5;
+        if (!finished && (it >= tgt || (!gs && (stop_on_good & 1) && is_good))) finished = true;
         __syncthreads();
-        if (tid == 0) { flags[0] = 0; flags[2] = 0; flags[1] = finished ? 1 : 0; }
-        __syncthreads();
+        if (tid == 0) {
+            int fin = finished ? 1 : 0;
+            if (gs && !finished) {
+                const uint32_t* hd = recs - kRecHeaderWords;
+                const int* iters0 = reinterpret_cast<const int*>(((unsigned long long)hd[1] << 32) | hd[0]);
+                int* gwords = reinterpret_cast<int*>(((unsigned long long)hd[3] << 32) | hd[2]);
+                const int G = (int)hd[4];
+                const int g = f / G;
+                fin = group_decide(gwords + 2 * ((int)(iters - iters0) / G + g), min(G, n_frames - g * G), it, is_good) != 0;
+            }
+            flags[0] = 0; flags[2] = 0; flags[1] = fin;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); // LDS only: the group report above is not waited for (ldpc_kernel.hpp, frame_barrier_lds)
+        if (gs) finished = flags[1] != 0;
         if (finished && other_flags[1]) break;
 
         // ---- one update sweep ----
