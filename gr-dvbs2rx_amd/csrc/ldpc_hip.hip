@@ -172,6 +172,33 @@ LdpcDecoderHip::LdpcDecoderHip(const LdpcTableDesc* table, int out_bits_message,
         // Two-level walk (check_node_hazard): ONE pair of hazard entries is closer than every other pair by a factor of two or more.
         // It goes first (entries 0, 1); word 2 of the record = the distance of the nearest OTHER pair = rows per outer block.
         uint32_t block2 = 0;
+        // (the degree class 32 without the heavy-hazard paths walks the near pair as a lane chain inside the outer blocks -- the
+        // two-level lane chain of check_node_hazard: the pair additionally has to be oriented like a single-pair chain, bit 12)
+        // (not in the 80-VGPR build -- same rule as where dense_ is set below --: the chain's state does not fit there, 76 -> 349 spilled registers)
+        bool dense_here = !pr_ && sched_.N < 64800 && dmax_ == 12 && 10 * sched_.conflict_layers >= 7 * sched_.q && 4 * half_lds_bytes(sched_.N) <= 160 * 1024;
+        if (const char* e = getenv("DVBS2_DENSE")) dense_here = !pr_ && dmax_ == 12 && atoi(e) != 0 && 4 * half_lds_bytes(sched_.N) <= 160 * 1024;
+        const bool tlc_build = tlc_class(dmax_) && !hz2_ && !pr_ && !dense_here;
+        if (tlc_build && two_level_on && L.block < 360 && L.block <= lane_chain_max && (nc_code == 4 || nc_code == 8) &&
+            (sched_.N / 360) * kSvWords >= lane_chain_words(L.block)) {
+            int best_a = -1, best_b = -1, d1 = 360, d2 = 360;
+            for (int a = 0; a < L.n_conflict; a++)
+                for (int b = a + 1; b < L.n_conflict; b++) {
+                    const LdpcEntry& ea = sched_.entries[L.entry_off + a], & eb = sched_.entries[L.entry_off + b];
+                    if (ea.base != eb.base) continue;
+                    const int d = std::abs((int)ea.rot - (int)eb.rot), dist = std::min(d, 360 - d);
+                    if (dist < d1) { d2 = d1; d1 = dist; best_a = a; best_b = b; }
+                    else d2 = std::min(d2, dist);
+                }
+            if (best_a >= 0 && d1 == L.block && d2 >= 2 * d1 && 360 / d1 - 360 / d2 >= 3) {
+                const int D = ((int)sched_.entries[L.entry_off + best_a].rot - (int)sched_.entries[L.entry_off + best_b].rot + 360) % 360;
+                if (D != L.block) std::swap(best_a, best_b); // entry 0's bit of row r = entry 1's bit of row r + block  <=>  (rot0 - rot1) mod 360 == block
+                block2 = (uint32_t)d2;
+                chain = 1;
+                order[0] = best_a; order[1] = best_b;
+                int n = 2;
+                for (int k = 0; k < L.n_conflict; k++) if (k != best_a && k != best_b) order[n++] = k;
+            }
+        }
         if (hz2_ && two_level_on && L.block < 360 && nc_code >= 4 && nc_code != (uint32_t)kHazardWalk && (L.cnt + 2 < 29 || nc_code == 8)) {
             int best_a = -1, best_b = -1, d1 = 360, d2 = 360;
             for (int a = 0; a < L.n_conflict; a++)

@@ -288,6 +288,16 @@ constexpr int kLowRegMinDmax =
           // the class is bound by VALU issue, not by its scratch traffic, and the form costs ~18 % more VALU work per edge
 #endif
 template <int DMAX, bool HZ2> constexpr bool kLowReg = DMAX >= kLowRegMinDmax;
+// two-level lane chain (check_node_hazard): the degree class 32 without the heavy-hazard paths (9/10 normal); not in the builds with software
+// frame barriers, which only tables without hazard layers run (S2X 154/180 lost 2.5 % to the larger kernel)
+// Which degree classes carry it is MEASURED (MI355X, interleaved A/B of whole tables, notes/r03_experiments.md): at run time the chain is
+// never slower than the ordered steps it replaces (9/10 normal + 13 %, 3/5 normal + 10 %, short 5/6 + 4 %, 3/4 normal + 2.4 %), but
+// compiling it in costs the packed / one-frame builds of the classes 12 and 28 eight percent on every table (2/3, T2 2/3, 8/9 normal)
+// and the class 20 what its one table gains -- so: 16 (3/4 normal + 5 % net, short 5/6 + 2 %, short 2/3 - 4 %), 24 (5/6 normal + 1.3 %),
+// 32 (9/10 normal + 8 %).
+template <int DMAX, bool HZ2> constexpr bool kTlc = (DMAX == 16 || DMAX == 24 || DMAX == 32) && !HZ2;
+__host__ __device__ constexpr bool tlc_class(int dmax) { return dmax == 16 || dmax == 24 || dmax == 32; }
+constexpr int kTlcLowRegMinDmax = 24; // from this degree class on a two-level-chain layer keeps its regular entries in the low-register form
 __device__ __forceinline__ int pm_pack(int magp, int d) { return (int)__builtin_amdgcn_perm((uint32_t)magp, (uint32_t)d, 0x0c0c0400u); } // d.b0 | magp.b0 << 8
 __device__ __forceinline__ int pm_inp(int pm) { return __builtin_amdgcn_sbfe(pm, 0, 8); }
 __device__ __forceinline__ int pm_min_clamped(int p) { return clamp_mag((int)((uint32_t)p >> 8) - 1); } // R2 on a minimum: clamp(|x| - 1, 0, 126)
@@ -590,20 +600,32 @@ __device__ __forceinline__ void check_node_chain_v2(const uint32_t* ent /*S0w[DM
         // rows past 359 read the padding of the table and log into the padding: no per-lane predicate in the loop
         const float4* rp = rec + jj + B;
         float* lp = logv + jj + B;
-        float4 r = *rp;
         const int nsteps = (kM - 1) / B; // rows jj + k B, k = 1 .. nsteps (the last one may lie in the padding)
         __builtin_amdgcn_s_setprio(3);
-#pragma unroll 4
-        for (int k = 0; k < nsteps; k++) {
-            const float4 rc = r;
-            rp += B;
-            r = *rp; // next row's operands, in flight during this step
+        auto step = [&](const float4 rc) {
             *lp = c; lp += B;
             const float x = __builtin_fmaf(c, rc.x, rc.y);
             const float w = vmed3_f32(x, -rc.z, rc.z);
             const float f = w - vmed3_f32(w, -1.f, 1.f);
             c = vmed3_f32(rc.w + f, 0.f, 255.f);
+        };
+        // A step is six dependent instructions (~40 cycles of a lone wave), an LDS read takes 64-130: with the operands of only the
+        // NEXT row in flight the walk ran at the LDS latency (~150 cycles per step, cycle stamps of round 3: 26.6 k cycles for the 179
+        // steps of 3/4 normal's block-2 layer). Four rows are kept in flight; reads past the table (rows >= 360 + block) fetch
+        // whatever lies there and are never used.
+        float4 q0 = rp[0], q1 = rp[B], q2 = rp[2 * B], q3 = rp[3 * B];
+        rp += 4 * B;
+        int k = 0;
+        for (; k + 4 <= nsteps; k += 4) {
+            step(q0); q0 = rp[0];
+            step(q1); q1 = rp[B];
+            step(q2); q2 = rp[2 * B];
+            step(q3); q3 = rp[3 * B];
+            rp += 4 * B;
         }
+        if (k < nsteps) { step(q0); k++; }
+        if (k < nsteps) { step(q1); k++; }
+        if (k < nsteps) { step(q2); k++; }
         __builtin_amdgcn_s_setprio(0);
     }
     lds_barrier();
@@ -667,7 +689,8 @@ constexpr int kMaxHazardHz2 = 12;
 constexpr int kMaxHazard12Dmax = 28; // (the degree class 32 has the two-level walk only: twelve ordered entries on top of 30 edges do not fit its registers)
 constexpr int kHazardWalk = 15; // header code: too many hazard entries, fall back to the single-wave chunk walk
 template <int DEG, int NC, bool LAYER0, bool PR = false, bool LAST = false, bool TWO = false /*two-level walk compiled in*/,
-          bool LR = false /*low-register form (see check_node_lr): regular entries keep one packed word, their addresses are computed twice*/>
+          bool LR = false /*low-register form (see check_node_lr): regular entries keep one packed word, their addresses are computed twice*/,
+          bool TLC = false /*two-level walk with the near pair as a LANE CHAIN (round 3), see below*/>
 __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, const uint32_t* ent, int jj, int lb, bool work,
                                                   int block, int block2 /*two-level walk: rows per outer block, 0 = off*/, const uint32_t* mw, uint32_t* nm, int own_in, int* carry,
                                                   uint32_t* tab /*lane_chain_words(block) of LDS scratch when the layer is a lane chain*/,
@@ -854,6 +877,113 @@ __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, con
             if (jj + block >= kM) lds_wr(ad[0], sat_sum_u8(inp[0], hout[0]));
         }
     }
+    // TWO-LEVEL LANE CHAIN (NC >= 4, block2 > 0, header bit 12; degree class 32 without the heavy-hazard paths). As in the two-level
+    // walk below, ONE pair of ordered entries (0, 1; host-ordered: entry 0's bit of row r is entry 1's bit of row r + block) is closer
+    // than every other pair (>= block2 >= 2 block rows apart), and the rows are processed in outer blocks of block2 rows. Inside an
+    // outer block only the near pair is sequential -- and it is walked like a single-pair lane chain: the `block` lanes that own rows
+    // 0 .. block-1 carry the chained LLR in a register from row to row ACROSS the outer blocks, ~20 instructions per row, no LDS
+    // hand-over. Per outer block:
+    //   a  its rows read their far entries (final: the rows that share those bits lie in other outer blocks), fold them into the
+    //      partial minimum / sign, read entry 0 (untouched so far, or -- last `block` rows -- what a head wrote in the first outer
+    //      block) and publish {inp0, partial min, partial sign, message byte 1}; heads (first outer block) do their two-entry step | barrier
+    //   b  the chain lanes walk the rows of this outer block, logging what arrives at each row                               | barrier
+    //   c  its rows complete the near pair from the logged value, then the far entries (minimum over all other entries), and
+    //      write those LLRs                                                                                                  | barrier
+    // 9/10 normal, layer 5 (pairs 4, 53, 84, 86 rows apart): 90 eight-entry steps through LDS (~80 k cycles, a fifth of the sweep)
+    // become 7 outer blocks + 89 register steps.
+    constexpr bool kTlcBuilt = TLC && (NC == 4 || NC == 8) && !PR;
+    bool tlc = false;
+    if constexpr (kTlcBuilt) tlc = block2 > 0 && tab != nullptr; // wave-uniform
+    if constexpr (kTlcBuilt) if (tlc) {
+        uint8_t* ulog = reinterpret_cast<uint8_t*>(tab + kM + block);
+        int chained = 0x80;
+        const bool head = work && jj < block;
+        int rnext = jj + block; // chain lanes: the next row to visit
+        for (int sb = 0; sb < kM; sb += block2) {
+            const int sb_end = min(sb + block2, kM);
+            const bool in_sb = work && (uint32_t)(jj - sb) < (uint32_t)block2;
+            int minF = min0, signsF = signs;
+            if (in_sb) {
+                int Lh[NC];
+#pragma unroll
+                for (int k = 2; k < NC; k++) Lh[k] = lds_rd(ad[k]);
+                const int L0 = lds_rd(ad[0]);
+#pragma unroll
+                for (int k = 2; k < NC; k++) {
+                    inp[k] = min(max(Lh[k] - hmb[k], -128), 127);
+                    mg[k] = mag_offset(Lh[k], hmb[k]);
+                    signsF ^= inp[k];
+                    minF = min(minF, mg[k]);
+                }
+                inp[0] = min(max(L0 - hmb[0], -128), 127);
+                mg[0] = mag_raw(L0, hmb[0]);
+                if (head) { // (first outer block: block2 >= 2 block)
+                    const int L1 = lds_rd(ad[1]);
+                    inp[1] = min(max(L1 - hmb[1], -128), 127);
+                    mg[1] = mag_raw(L1, hmb[1]);
+                    int o0, o1;
+                    asm("v_med3_i32 %0, %1, 0, %2" : "=v"(o0) : "v"(mg[1]), "v"(minF));
+                    asm("v_med3_i32 %0, %1, 0, %2" : "=v"(o1) : "v"(mg[0]), "v"(minF));
+                    const int s0 = (signsF ^ inp[1]) >> 31, s1 = (signsF ^ inp[0]) >> 31;
+                    hout[0] = (o0 ^ s0) - s0;
+                    hout[1] = (o1 ^ s1) - s1;
+                    chained = sat_sum_u8(inp[0], hout[0]);
+                    lds_wr(ad[1], sat_sum_u8(inp[1], hout[1]));
+                } else
+                    tab[jj] = ((uint32_t)inp[0] & 0x1ffu) | ((uint32_t)minF << 9) | (((uint32_t)signsF >> 31) << 16) | ((uint32_t)hmb[1] << 24);
+            }
+            lds_barrier();
+            if (head && rnext < sb_end) {
+                uint32_t t = tab[rnext];
+                for (; rnext < sb_end; rnext += block) {
+                    const uint32_t tc = t;
+                    t = tab[rnext + block]; // next row's record (valid when that row belongs to this outer block; reloaded otherwise)
+                    const int i0 = (int)(tc << 23) >> 23, P = (int)((tc >> 9) & 0x7fu), m1 = (int)(tc >> 24);
+                    const int sw = (int)(tc << 15);
+                    ulog[rnext] = (uint8_t)chained;
+                    const int i1 = min(max(chained - m1, -128), 127);
+                    const int g1 = mag_raw(chained, m1);
+                    int o0;
+                    asm("v_med3_i32 %0, %1, 0, %2" : "=v"(o0) : "v"(g1), "v"(P));
+                    const int s0 = (sw ^ i1) >> 31;
+                    chained = sat_sum_u8(i0, (o0 ^ s0) - s0);
+                }
+            }
+            lds_barrier();
+            if (in_sb) {
+                if (!head) {
+                    const int L1 = ulog[jj];
+                    inp[1] = min(max(L1 - hmb[1], -128), 127);
+                    mg[1] = mag_raw(L1, hmb[1]);
+                    int o0, o1;
+                    asm("v_med3_i32 %0, %1, 0, %2" : "=v"(o0) : "v"(mg[1]), "v"(minF));
+                    asm("v_med3_i32 %0, %1, 0, %2" : "=v"(o1) : "v"(mg[0]), "v"(minF));
+                    const int s0 = (signsF ^ inp[1]) >> 31, s1 = (signsF ^ inp[0]) >> 31;
+                    hout[0] = (o0 ^ s0) - s0;
+                    hout[1] = (o1 ^ s1) - s1;
+                    lds_wr(ad[1], sat_sum_u8(inp[1], hout[1]));
+                    if (jj + block >= kM) lds_wr(ad[0], sat_sum_u8(inp[0], hout[0])); // last row of its chain: final writer of that bit
+                }
+                mg[0] = clamp_mag(mg[0]); mg[1] = clamp_mag(mg[1]); // (raw above; everything below and after the loop takes clamped ones)
+                const int xall = signsF ^ inp[0] ^ inp[1];
+                int pre[NC + 1], suf[NC + 1];
+                pre[0] = min0; suf[NC] = 127;
+#pragma unroll
+                for (int k = 0; k < NC; k++) pre[k + 1] = min(pre[k], mg[k]);
+#pragma unroll
+                for (int k = NC - 1; k >= 0; k--) suf[k] = min(suf[k + 1], mg[k]);
+#pragma unroll
+                for (int k = 2; k < NC; k++) {
+                    const int other = min(pre[k], suf[k + 1]);
+                    const int sg = (xall ^ inp[k]) >> 31;
+                    const int out = (other ^ sg) - sg;
+                    hout[k] = out;
+                    lds_wr(ad[k], sat_sum_u8(inp[k], out));
+                }
+            }
+            if (sb + block2 < kM) lds_barrier(); // the next outer block reads what this one wrote
+        }
+    }
     // TWO-LEVEL WALK (NC >= 4, block2 > 0). The block size B is the distance of the NEAREST hazard pair only; every other pair
     // of hazard entries is at least block2 >= 2 B rows apart. So the rows are walked in outer blocks of block2 rows: at its start the
     // rows of an outer block read their FAR hazard entries (2 .. NC-1: final with respect to all earlier outer blocks, untouched
@@ -920,8 +1050,8 @@ __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, con
             if ((sb >> 6) != ((sb + 2 * block2 - 1) >> 6)) lds_barrier();
         }
     }
-    int rel = (work && !lane_chain && !two_level) ? jj : 0x40000000;
-    for (int start = (lane_chain || two_level) ? kM : 0; start < kM; start += block, rel -= block) {
+    int rel = (work && !lane_chain && !two_level && !tlc) ? jj : 0x40000000;
+    for (int start = (lane_chain || two_level || tlc) ? kM : 0; start < kM; start += block, rel -= block) {
         if ((uint32_t)rel < (uint32_t)block) {
             if constexpr (NC == 2) {
                 // two hazard entries: each one's magnitude sent back is min(partial min0, the other's magnitude) =
@@ -1055,8 +1185,15 @@ __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, con
         DVBS2_CHAIN_CASE(27) DVBS2_CHAIN_CASE(28) DVBS2_CHAIN_CASE(29) DVBS2_CHAIN_CASE(30) DVBS2_CHAIN_CASE(31) DVBS2_CHAIN_CASE(32) \
         default: break; }
 
+// (A layer that runs the two-level lane chain gets an instantiation of its own -- TLC and the low-register form, which keeps one
+// word per regular entry across the outer blocks instead of three --: compiled into the common instantiation the chain's register
+// state made the compiler spill the regular entries of EVERY four- and eight-entry layer around it, 9/10 normal's multi-pair
+// layers went from 12-17 k to 25-34 k cycles.)
+#define DVBS2_HAZ_CALL1(D, NCV, LRV, TLCV) { \
+        if (layer0) check_node_hazard<D, NCV, true, false, false, HZ2, LRV, TLCV>(lds_all, ent, jj, lb, work, block, block2, mw, nm, 0, nullptr, htab, hb_ctr, hb_epoch, hb_lane, hz_ph); else check_node_hazard<D, NCV, false, false, false, HZ2, LRV, TLCV>(lds_all, ent, jj, lb, work, block, block2, mw, nm, 0, nullptr, htab, hb_ctr, hb_epoch, hb_lane, hz_ph); }
 #define DVBS2_HAZ_CALL(D, NCV) { if constexpr (D - 2 >= NCV) { \
-        if (layer0) check_node_hazard<D, NCV, true, false, false, HZ2, kLowReg<DMAX, HZ2>>(lds_all, ent, jj, lb, work, block, block2, mw, nm, 0, nullptr, htab, hb_ctr, hb_epoch, hb_lane, hz_ph); else check_node_hazard<D, NCV, false, false, false, HZ2, kLowReg<DMAX, HZ2>>(lds_all, ent, jj, lb, work, block, block2, mw, nm, 0, nullptr, htab, hb_ctr, hb_epoch, hb_lane, hz_ph); } }
+        if constexpr (kTlc<DMAX, HZ2> && !SOFT && MINW == 1 && (NCV == 4 || NCV == 8)) { if (block2 > 0 && htab != nullptr) DVBS2_HAZ_CALL1(D, NCV, (DMAX >= kTlcLowRegMinDmax), true) else DVBS2_HAZ_CALL1(D, NCV, (kLowReg<DMAX, HZ2>), false) } \
+        else DVBS2_HAZ_CALL1(D, NCV, (kLowReg<DMAX, HZ2>), false) } }
 #define DVBS2_HAZ_CASE(D) case D: if constexpr (D >= 4 && D <= DMAX && D > DMAX - 8) { \
         if (nc == 2) DVBS2_HAZ_CALL((D >= 4 ? D : 4), 2) else if (nc == 4) DVBS2_HAZ_CALL((D >= 4 ? D : 4), 4) else { if constexpr (HZ2 && DMAX <= kMaxHazard12Dmax) { if (nc == 8) DVBS2_HAZ_CALL((D >= 4 ? D : 4), 8) else DVBS2_HAZ_CALL((D >= 4 ? D : 4), 12) } else DVBS2_HAZ_CALL((D >= 4 ? D : 4), 8) } } break;
 #define DVBS2_HAZ_SWITCH switch (deg) { \
@@ -1433,7 +1570,7 @@ __global__ __launch_bounds__(SOLO ? kSoloThreads : kThreads, SOLO ? 4 : MINW) vo
             uint32_t* htab = ((hdr >> 12) & 1u) ? sv : nullptr; // lane-chain scratch: the sign-vector area is idle during a sweep
             const int block = (int)(hdr >> 16);
             int block2 = 0; // hazard layers: rows per outer block of the two-level walk (0: off)
-            if constexpr (HZ2) { if (block < kM) block2 = (int)wr[(size_t)i * RSW + 2]; }
+            if constexpr (HZ2 || (kTlc<DMAX, HZ2> && !SOFT && MINW == 1)) { if (block < kM) block2 = (int)wr[(size_t)i * RSW + 2]; }
             const bool layer0 = (i == 0);
             const int mso = i * kLayerBytes; // scalar byte offset of this layer's message records
             TSTAMP(tA);
