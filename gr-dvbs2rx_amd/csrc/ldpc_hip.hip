@@ -347,7 +347,9 @@ LdpcDecoderHip::LdpcDecoderHip(const LdpcTableDesc* table, int out_bits_message,
         HIP_OK(hipMalloc(&d_gsync_, (size_t)(max_frames_ / G_ + 2) * 8));
         resolve_rounds_ = 0;
         const unsigned long long a = (unsigned long long)d_iters_, b = (unsigned long long)d_gsync_;
-        const uint32_t hd[kRecHeaderWords] = { (uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32), (uint32_t)G_, 0, 0, 0 };
+        int spin_max = kGroupSpinMax;
+        if (const char* e = getenv("DVBS2_GROUP_SPIN_MAX")) spin_max = std::max(0, atoi(e)); // tests: 0 = a waiting member gives up at once (fallback path)
+        const uint32_t hd[kRecHeaderWords] = { (uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32), (uint32_t)G_, (uint32_t)spin_max, 0, 0 };
         HIP_OK(hipMemcpy(d_recs_alloc_, hd, sizeof(hd), hipMemcpyHostToDevice));
     }
     if (const char* e = getenv("DVBS2_RESOLVE_ROUNDS")) resolve_rounds_ = std::max(0, std::min(8, atoi(e))); // tests: 0 forces the host-side leftover path

@@ -32,7 +32,7 @@ __host__ __device__ constexpr int rec_stride_wave(int dmax) { return 2 * dmax + 
 // and the group size. Kept out of the kernel's argument list on purpose: arguments stay live in SGPRs for the whole kernel, and the
 // one-frame builds of the degree class 16 answered three more of them with 25 more spilled scalars and 2-3 % (measured); here they are
 // fetched with two scalar loads once per update, by the lane that reports.
-constexpr int kRecHeaderWords = 8; // [0,1] iters base, [2,3] group words base, [4] group size, rest unused
+constexpr int kRecHeaderWords = 8; // [0,1] iters base, [2,3] group words base, [4] group size, [5] polls before a waiting member gives up, rest unused
 // per frame: N LLR bytes, then the sign-vector area (syndrome test; scratch of the ordered hazard phases during a sweep:
 // at least kChainScratchWords dwords, which is what short frames get instead of their small sign-vector area), then 8 flag words
 constexpr int kChainMaxBlock = 128;                                             // largest block walked as a register chain
@@ -85,7 +85,7 @@ constexpr int kGroupSpinMax = 1 << 12; // polls of ~2 us
 // only the two words themselves carry information, both live in one 8-byte slot (one cache line, one coherence point, and a
 // member's two updates are issued in order by one lane), and the reader fetches `lastbad` with an atomic read-modify-write after
 // it has seen the arrival count, so it observes every `lastbad` update of the members it counted.
-__device__ __forceinline__ int group_decide(int* gw /*{arrive, lastbad} of this frame's group*/, int members, int it, bool good)
+__device__ __forceinline__ int group_decide(int* gw /*{arrive, lastbad} of this frame's group*/, int members, int it, bool good, int spin_max = kGroupSpinMax)
 {
     if (!good) {
         __hip_atomic_fetch_max(gw + 1, it + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -99,7 +99,7 @@ __device__ __forceinline__ int group_decide(int* gw /*{arrive, lastbad} of this 
         // failing pre-test skips the full test)
         if (__hip_atomic_fetch_max(gw + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > it) return 0;
         if (__hip_atomic_load(gw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) break;
-        if (spin > kGroupSpinMax) return 2;
+        if (spin >= spin_max) return 2;
         __builtin_amdgcn_s_sleep(8);
     }
     return __hip_atomic_fetch_max(gw + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= it ? 1 : 0;
@@ -1215,6 +1215,26 @@ __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, con
 // -- always two per SIMD -- and lets two of them leave at once: a workgroup keeps both waves on one pair of SIMDs and one
 // wave on the other pair, and workgroups sharing a CU take complementary patterns (a counter pair per CU in global memory).
 // Result: three working waves per SIMD again, but the frames no longer wait for each other. Needs <= 128 VGPRs.
+// Step 1 of the full syndrome test (see the kernel): the 360-bit sign vectors of all N / 360 groups, one thread per eight consecutive
+// LLR bytes; returns non-zero when one of this thread's bytes is a zero LLR. A function of its own, NOT inlined: inlined, its loop
+// perturbed the register allocation of the sweep and cost the never-converging batches -- where it never runs -- up to 4 % (S2X 154/180).
+__device__ __attribute__((noinline)) int syndrome_sign_vectors(const uint8_t* lds, uint32_t* sv, int N, int tid)
+{
+    uint8_t* svb = reinterpret_cast<uint8_t*>(sv);
+    int zero = 0;
+#pragma unroll 2
+    for (int blk = tid; blk < N / 8; blk += kHalf) {
+        const uint2 v = *reinterpret_cast<const uint2*>(lds + 8 * blk);
+        const uint32_t xa = v.x ^ 0x80808080u, xb = v.y ^ 0x80808080u; // two's complement: zero bytes = zero LLRs
+        zero |= (int)((((xa - 0x01010101u) & ~xa) | ((xb - 0x01010101u) & ~xb)) & 0x80808080u);
+        // sign bit of byte i -> bit i (offset binary: negative <=> bit 7 clear): bits 0, 8, 16, 24 gathered by a multiply
+        const uint32_t na = (((~v.x & 0x80808080u) >> 7) * 0x01020408u) >> 24, nb = (((~v.y & 0x80808080u) >> 7) * 0x01020408u) >> 24;
+        const int g = blk / 45;
+        svb[g * (kSvWords * 4) + (blk - 45 * g)] = (uint8_t)((na & 0xfu) | ((nb & 0xfu) << 4));
+    }
+    return zero;
+}
+
 constexpr int kSoloThreads = 512;
 __device__ __forceinline__ uint32_t hw_cu_index()
 {
@@ -1450,20 +1470,14 @@ __global__ __launch_bounds__(SOLO ? kSoloThreads : kThreads, SOLO ? 4 : MINW) vo
         const bool full_any = flags[3] != 0 || (!soft_bar && !SOLO && other_flags[3] != 0); // uniform over the barrier domain
         if (full_any) {
         if (need_full) {
-            // Step 1: 360-bit sign vector per group via wave ballots (4 groups per trip to batch the LDS reads).
-            unsigned long long zero_any = 0;
-            for (int g0 = 0; g0 < NG; g0 += 4) {
-                uint32_t v[4];
-#pragma unroll
-                for (int u = 0; u < 4; u++) v[u] = (active && g0 + u < NG) ? lds[kM * (g0 + u) + tid] : 0xffu;
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const unsigned long long neg = __ballot(v[u] < 0x80u);
-                    zero_any |= __ballot(v[u] == 0x80u);
-                    if (lane == 0 && g0 + u < NG) *reinterpret_cast<uint2*>(&sv[(g0 + u) * kSvWords + 2 * wave]) = make_uint2((uint32_t)neg, (uint32_t)(neg >> 32));
-                }
+            // Step 1: 360-bit sign vector per group. Round 3: one thread per EIGHT consecutive LLR bytes (one 8-byte LDS read -> one
+            // byte of the vector: 360 = 45 x 8, so a block never straddles two groups) instead of one byte read and two ballots per
+            // thread and group -- a fifth of the LDS instructions; at the operating point, where nearly every test is a full one,
+            // the tests were a tenth of the decode (cycle stamps).
+            {
+                const int zero = syndrome_sign_vectors(lds, sv, N, tid);
+                if (__ballot(zero != 0) != 0 && lane == 0) flags[0] = 1;
             }
-            if (zero_any != 0 && lane == 0) flags[0] = 1;
         }
         TSTAMP(tC); tm_s1 += tC - tS0;
         lds_barrier();
@@ -1476,6 +1490,8 @@ __global__ __launch_bounds__(SOLO ? kSoloThreads : kThreads, SOLO ? 4 : MINW) vo
         lds_barrier();
         if (need_full) {
             // Step 2: parity word (layer i, lanes 32w..32w+31) = xor over entries of the rotated sign vectors
+            // (this one stays inline: as a function of its own its record arrays made the degree classes 12-dense and 32 two to
+            // three times slower -- the kernel then has to provide the callee's registers on top of its own)
             int bad = 0;
             for (int item = tid; item < q * 12; item += kHalf) {
                 const int i = item / 12, w = item - 12 * i;
@@ -1516,7 +1532,7 @@ __global__ __launch_bounds__(SOLO ? kSoloThreads : kThreads, SOLO ? 4 : MINW) vo
                 int* gwords = reinterpret_cast<int*>(((unsigned long long)hd[3] << 32) | hd[2]);
                 const int G = (int)hd[4];
                 const int g = f / G; // within this launch (its first frame is a multiple of the group size)
-                fin = group_decide(gwords + 2 * ((int)(iters - iters0) / G + g), min(G, n_frames - g * G), it, is_good) != 0;
+                fin = group_decide(gwords + 2 * ((int)(iters - iters0) / G + g), min(G, n_frames - g * G), it, is_good, (int)hd[5]) != 0;
             }
             flags[0] = 0; flags[2] = 0; flags[1] = fin;
         }

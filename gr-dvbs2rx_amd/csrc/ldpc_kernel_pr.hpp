@@ -286,7 +286,7 @@ __global__ __launch_bounds__(kThreads, 6) void ldpc_layered_pr_kernel(
                 int* gwords = reinterpret_cast<int*>(((unsigned long long)hd[3] << 32) | hd[2]);
                 const int G = (int)hd[4];
                 const int g = f / G;
-                fin = group_decide(gwords + 2 * ((int)(iters - iters0) / G + g), min(G, n_frames - g * G), it, is_good) != 0;
+                fin = group_decide(gwords + 2 * ((int)(iters - iters0) / G + g), min(G, n_frames - g * G), it, is_good, (int)hd[5]) != 0;
             }
             flags[0] = 0; flags[2] = 0; flags[1] = fin;
         }

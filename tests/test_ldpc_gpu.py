@@ -515,3 +515,20 @@ def test_two_devices_from_one_process():
         assert np.array_equal(o.cpu().numpy(), want[64 * d:64 * d + 64])
         assert np.array_equal(b.cpu().numpy(), T.pack_bits(want[64 * d:64 * d + 64], K))
         dec.close()
+
+
+@pytest.mark.parametrize("table,amp,sigma", [("S2_TABLE_B4", 6, 5.2), ("S2_TABLE_C1", 5, 6.0)])
+def test_group_stop_fallback_when_members_give_up(monkeypatch, table, amp, sigma):
+    """The group-synchronous stop (csrc/ldpc_kernel.hpp, group_decide) lets a frame that passes its test wait for the other frames of
+    its group; if they do not report in time it stops at its own good point and the host-side resolution (targets kernel + resume
+    launches, finish()) completes the group. DVBS2_GROUP_SPIN_MAX=0 makes every waiting frame give up at once: near-threshold
+    groups (frames converge at different counts) must still come out exactly like the reference's lockstep batch, for G = 32 and 16,
+    with and without enqueued resolution rounds."""
+    monkeypatch.setenv("DVBS2_GROUP_SPIN_MAX", "0")
+    llr, _ = T.llr_codeword_awgn(table, 96, 99, amp=amp, sigma=sigma)
+    llr[70] = T.llr_noise(1, llr.shape[1], 3)[0]
+    for rounds in ("2", "0"):
+        monkeypatch.setenv("DVBS2_RESOLVE_ROUNDS", rounds)
+        r32 = compare(table, llr, 32, 50)
+        compare(table, llr[:80], 16, 30)
+        assert len(set(r32.tolist())) > 1
