@@ -1,9 +1,9 @@
 // bbdeheader_hip.hip -- see bbdeheader_hip.h. Three launches per call:
 //   1  bbdh_header_kernel   one thread per BBFRAME: CRC-8 over the ten header bytes, field checks (parse_bbheader)
-//   2  bbdh_scan_kernel     ONE thread walks the frames in order: the block's state machine (synched / partial count, gap and
-//                           resync rules, general_work :160-247) reduced to what it decides -- where packets start, how many,
-//                           where the head of a packet that straddles two BBFRAMEs lies. ~30 instructions per frame; 4096
-//                           frames take about as long as one LDPC sweep of one frame.
+//   2  bbdh_scan_kernel     the block's state machine (synched / partial count, gap and resync rules, general_work :160-247) reduced to
+//                           what it decides -- where packets start, how many, where the head of a packet that straddles two BBFRAMEs
+//                           lies. One workgroup: the healthy prefix of the call as two prefix sums over 256 threads (verified frame by
+//                           frame), the rest (from the first gap / bad header / resync on) in order on one thread.
 //   3  bbdh_packet_kernel   one workgroup per BBFRAME, one thread per TS packet: gather (at most two pieces), CRC-8, restore
 //                           the sync byte, set the transport error indicator on a failed check.
 // The byte work is tiny next to the decoders in front of it (kbch / 8 bytes per frame in, about as many out): no tuning beyond
@@ -47,15 +47,86 @@ __global__ void bbdh_header_kernel(const uint8_t* __restrict__ in, int n_frames,
     hdr[f] = valid ? (int)(1u | ((dfl / 8) << 1) | ((syncd / 8) << 16)) : 0; // dfl / 8 <= 8 089 (14 bits), syncd / 8 <= 8 191
 }
 
-__global__ void bbdh_scan_kernel(const int* __restrict__ hdr, int n_frames, int kbch_bytes, BbdhState* __restrict__ st, BbdhPlan* __restrict__ plan)
+// The block's state machine over the frames of a call. Its state is (synched, bytes of a partial packet carried over); what a frame
+// does to it depends on its header alone. In a HEALTHY stream -- every header valid, DFL >= one packet, SYNCD consistent with the
+// carried bytes (general_work :194-199) -- nothing is skipped or dropped, so the carried byte count entering frame f is
+//   p_in(f) = (p_in(0) + sum of DFL/8 of the frames before f) mod 188,
+// frame f completes (p_in + DFL/8) / 188 packets, and the head of its first packet lies at the end of frame f - 1. That is two prefix
+// sums: 256 threads compute them speculatively, verify every frame against its header (valid, DFL >= 188 bytes, SYNCD/8 == 187 - p_in
+// unless p_in == 0) and write the plans of all frames BEFORE the first one that fails; from there on (a gap, a bad header, a short
+// DATAFIELD, or the whole call while the block is not synchronised yet) one thread walks the frames in order exactly like round 2
+// (~30 instructions per frame, started from the exact state the prefix gives). Round 2 walked every frame of every call on one thread
+// (65535 frames: ~4 ms on the critical stream).
+constexpr int kScanThreads = 256;
+__device__ __forceinline__ int block_excl_scan(int v, int* sh, int tid, int* total)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    int synched = st->synched, partial = st->partial;
-    int part_frame = -1, part_off = 0; // where the carried partial bytes lie (-1: st->partial_pkt)
-    unsigned long long packets = 0, dropped = 0, gaps = 0, overruns = 0;
-    int out_pkts = 0;
-    int h_next = n_frames > 0 ? hdr[0] : 0;
-    for (int f = 0; f < n_frames; f++) {
+    sh[tid] = v;
+    __syncthreads();
+    for (int d = 1; d < kScanThreads; d <<= 1) {
+        const int t = tid >= d ? sh[tid - d] : 0;
+        __syncthreads();
+        sh[tid] += t;
+        __syncthreads();
+    }
+    const int incl = sh[tid];
+    if (total) *total = sh[kScanThreads - 1];
+    __syncthreads();
+    return incl - v;
+}
+__global__ __launch_bounds__(kScanThreads) void bbdh_scan_kernel(const int* __restrict__ hdr, int n_frames, int kbch_bytes, BbdhState* __restrict__ st, BbdhPlan* __restrict__ plan)
+{
+    __shared__ int sh[kScanThreads];
+    __shared__ int s_first_bad, s_part, s_part_frame, s_part_off, s_out_pkts;
+    const int tid = threadIdx.x;
+    const int synched0 = st->synched, partial0 = st->partial;
+    const int per = (n_frames + kScanThreads - 1) / kScanThreads;
+    const int c0 = min(tid * per, n_frames), c1 = min(c0 + per, n_frames);
+    if (tid == 0) { s_first_bad = synched0 ? n_frames : 0; s_part = partial0; s_part_frame = -1; s_part_off = 0; s_out_pkts = 0; }
+    // carried bytes entering this thread's chunk (mod 188)
+    int bytes = 0;
+    for (int f = c0; f < c1; f++) bytes = (bytes + ((hdr[f] >> 1) & 0x7fff)) % kTsLen;
+    int dummy;
+    const int before = block_excl_scan(bytes, sh, tid, &dummy); // (sums of residues: at most 256 * 187)
+    // verification + packets per chunk
+    int p = (partial0 + before) % kTsLen, pk = 0, bad = n_frames;
+    for (int f = c0; f < c1; f++) {
+        const int h = hdr[f], dfl8 = (h >> 1) & 0x7fff, syncd8 = (h >> 16) & 0xffff;
+        const bool ok = (h & 1) && dfl8 >= kTsLen && (p == 0 || syncd8 == kTsLen - 1 - p);
+        if (!ok && bad == n_frames) bad = f;
+        pk += (p + dfl8) / kTsLen;
+        p = (p + dfl8) % kTsLen;
+    }
+    if (bad < n_frames) atomicMin(&s_first_bad, bad);
+    const int pk_before = block_excl_scan(pk, sh, tid, &dummy); // (exact for every chunk that starts at or before the first failing frame)
+    const int first_bad = s_first_bad;
+    // plans of the healthy prefix; the thread whose chunk holds `first_bad` (or the end of the call) leaves the state there
+    p = (partial0 + before) % kTsLen;
+    int out_pkts = pk_before;
+    for (int f = c0; f < c1 && f < first_bad; f++) {
+        const int dfl8 = (hdr[f] >> 1) & 0x7fff;
+        BbdhPlan pl;
+        pl.src_off = kBbHeaderBytes; pl.head = p; pl.head_frame = -1; pl.head_off = 0;
+        if (p > 0 && f > 0) { pl.head_frame = f - 1; pl.head_off = kBbHeaderBytes + ((hdr[f - 1] >> 1) & 0x7fff) - p; }
+        pl.n_pkts = (p + dfl8) / kTsLen; pl.out_base = out_pkts;
+        plan[f] = pl;
+        out_pkts += pl.n_pkts;
+        p = (p + dfl8) % kTsLen;
+    }
+    const int stop = min(first_bad, n_frames); // first frame the prefix does not cover
+    if (stop > 0 && c0 < stop && stop <= c1) { // this thread wrote the plan of frame stop - 1: the state after it
+        s_part = p; s_out_pkts = out_pkts;
+        s_part_frame = p > 0 ? stop - 1 : -1;
+        s_part_off = p > 0 ? kBbHeaderBytes + ((hdr[stop - 1] >> 1) & 0x7fff) - p : 0;
+    }
+    __syncthreads();
+    if (tid != 0) return;
+    // ---- in order from `first_bad` (general_work :160-247 reduced to what it decides per frame)
+    int synched = first_bad > 0 ? 1 : synched0, partial = s_part;
+    int part_frame = s_part_frame, part_off = s_part_off; // where the carried partial bytes lie (-1: st->partial_pkt)
+    out_pkts = s_out_pkts;
+    unsigned long long packets = (unsigned long long)out_pkts, dropped = 0, gaps = 0, overruns = 0;
+    int h_next = first_bad < n_frames ? hdr[first_bad] : 0;
+    for (int f = first_bad; f < n_frames; f++) {
         const int h = h_next;
         if (f + 1 < n_frames) h_next = hdr[f + 1];
         BbdhPlan pl; pl.src_off = 0; pl.head = 0; pl.head_frame = -1; pl.head_off = 0; pl.n_pkts = 0; pl.out_base = out_pkts;
@@ -168,7 +239,7 @@ int BbDeheaderHip::process_device(const uint8_t* d_bbframes, int n_frames, uint8
     DeviceGuard guard(device_);
     if (!guard.ok) { call_err_ = "hipSetDevice failed"; return -1; }
     hipLaunchKernelGGL(bbdh_header_kernel, dim3((n_frames + 255) / 256 + (n_frames == 0)), dim3(256), 0, stream, d_bbframes, n_frames, kbch_bytes_, max_dfl_, d_hdr_);
-    hipLaunchKernelGGL(bbdh_scan_kernel, dim3(1), dim3(1), 0, stream, d_hdr_, n_frames, kbch_bytes_, d_state_, d_plan_);
+    hipLaunchKernelGGL(bbdh_scan_kernel, dim3(1), dim3(kScanThreads), 0, stream, d_hdr_, n_frames, kbch_bytes_, d_state_, d_plan_);
     if (n_frames > 0) {
         hipLaunchKernelGGL(bbdh_packet_kernel, dim3(n_frames), dim3(64), 0, stream, d_bbframes, n_frames, kbch_bytes_, d_state_, d_plan_, d_out);
         hipLaunchKernelGGL(bbdh_save_partial_kernel, dim3(1), dim3(192), 0, stream, d_bbframes, n_frames, kbch_bytes_, d_state_, d_plan_);

@@ -184,6 +184,14 @@ def test_hip_fuzz_vs_oracle_with_random_call_sizes(kbch, seed):
     dev.reset()
     assert dev.counters() == T.OracleBbDeheader(kbch).counters()
     dev.close()
+    # the same stream in ONE call and in calls of 100 frames: the scan takes the healthy stretches as parallel prefix sums (several
+    # frames per thread) and everything from the first anomaly of a call on in order -- both against the stateful restatement
+    for step in (fr.shape[0], 100):
+        dev, orc = _hip(kbch, fr.shape[0]), T.OracleBbDeheader(kbch)
+        for i in range(0, fr.shape[0], step):
+            assert np.array_equal(dev.work(fr[i:i + step]), orc.work(fr[i:i + step])), (step, i)
+            assert dev.counters() == orc.counters(), (step, i)
+        dev.close()
 
 
 @pytest.mark.gpu
