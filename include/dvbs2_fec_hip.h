@@ -51,7 +51,9 @@ int dvbs2_device_count(void);
 
 /* Page-lock a host buffer that the block hands to the plain (host-pointer) entry points again and again -- e.g. a GNU
  * Radio input buffer, once, at start() -- so that the transfers run at PCIe speed and asynchronously (pageable memory
- * goes through a staging copy at a fraction of it and blocks the calling thread). Optional; undo before freeing. */
+ * goes through a staging copy at a fraction of it and blocks the calling thread). Optional; undo before freeing.
+ * dvbs2_ldpc_decode() also lands its results directly in bits_out / llr_out / ret when THOSE are page-locked (registered here or
+ * allocated with hipHostMalloc) instead of in pinned buffers of the handle that it copies out afterwards. */
 int dvbs2_host_register(void* p, size_t bytes);
 int dvbs2_host_unregister(void* p);
 
@@ -98,6 +100,9 @@ int dvbs2_ldpc_params(const dvbs2_ldpc_t* h, int* n, int* table_k, int* message_
  * ret          NULL or one int32 per group: what decode() returned for that batch -- trials left
  *              (max_trials - updates), or -1 when the cap was hit without convergence (:410-419)
  * n_frames need not be a multiple of G; a trailing partial group is a group of its own.
+ * The batch-coupled stopping rule (every frame of a group runs exactly as many updates as the reference's SIMD batch, :153 of
+ * lib/ldpc_decoder/layered_decoder.hh) is resolved on the device, inside the first launch for groups of up to 64 frames (the frames of a
+ * group agree after every syndrome test); results do not depend on how frames are scheduled.
  */
 int dvbs2_ldpc_decode(dvbs2_ldpc_t* h, const int8_t* llr_in, int n_frames, int max_trials, int out_mode,
                       uint8_t* bits_out, int8_t* llr_out, int32_t* ret);
