@@ -18,7 +18,10 @@ and the SURVEY 8(d) secondaries of config 2:
   config2_awgn  the operating point: valid codewords, QPSK + AWGN, LLR = clamp(rint(2 sqrt(2) y / N0)) (the demapper's map), groups
                 stop at different counts; mean updates and the roofline on the updates actually executed
   config2_host  the host-buffer entry dvbs2_ldpc_decode (H2D / D2H inclusive; pageable and page-locked caller buffers)
-plus `device_copy` (measured device-to-device copy bandwidth beside the 8 TB/s nominal peak).
+plus `device_copy` (measured device-to-device copy bandwidth beside the 8 TB/s nominal peak), `host_link` (plain hipMemcpyAsync rates of
+the box's host link: what the host entry could at most be fed with) and `roofline.mapping_ceiling` (the same kernel build on B4's
+hazard-free degree-7 sibling S2X_TABLE_B3, per edge update, projected onto B4: what this mapping does when nothing orders the rows).
+At N > 1 every rank additionally runs `config2_host` at the same time (per-rank and summed rates): the host feed of the sharded job.
 Every parity gate compares the WHOLE batch with the genuine reference run on all host cores (--gate first: first group only).
 config 1 (one frame through a CPU path) has no counterpart in the bench: the library has no CPU path by design; its
 workload runs on the HIP path in tests/test_ldpc_gpu.py::test_baseline_config1_one_frame_replicated.
@@ -213,6 +216,65 @@ def device_copy_bandwidth(torch, dev):
             "frac_of_nominal": 2 * n / ms / 1e6 / HBM_PEAK_GBS}
 
 
+def host_link_bandwidth(capi, local):
+    """Plain hipMemcpyAsync rate of this box's host link (dvbs2_measure_host_copy: no decode, no pipeline): 1 GiB of hipHostMalloc
+    memory over one and four streams, hipHostRegister'ed malloc memory (what dvbs2_host_register gives a caller), pageable memory."""
+    import ctypes as C
+    out = {"bytes": 1 << 30, "unit": "GB/s"}
+    for name, nbytes, streams, kind in (("hipHostMalloc_1_stream", 1 << 30, 1, 0), ("hipHostMalloc_4_streams", 1 << 30, 4, 0),
+                                        ("hipHostRegister_1_stream", 1 << 30, 1, 1), ("pageable_1_stream", 1 << 28, 1, 2)):
+        h2d, d2h = C.c_double(), C.c_double()
+        capi.check(capi.lib.dvbs2_measure_host_copy(local, nbytes, streams, kind, C.byref(h2d), C.byref(d2h)))
+        out[name] = {"h2d": h2d.value, "d2h": d2h.value}
+    return out
+
+
+def host_entry(np, torch, capi, LdpcDecoder, T, dev, local, N, out_bytes, nf, trials, G, stream, steps2, sizes, shard=None):
+    """dvbs2_ldpc_decode (host buffers in and out) beside the resident rate of the same frames: pageable and page-locked caller buffers.
+    With `shard` (N > 1) every rank starts its calls together, so that the ranks' transfers compete for the host like in a receiver."""
+    d = LdpcDecoder(standard=capi.STANDARD_DVBS2, framesize=capi.FECFRAME_NORMAL, rate="C1_2", outputmode=capi.OM_MESSAGE,
+                    max_trials=trials, group_size=G, max_frames=nf, device=local)
+    host = {}
+    for frames in sizes:
+        xh = noise_llr(torch, frames, N, dev, 12345).cpu().numpy()
+        for mode in ("pageable", "registered"):
+            bits_h = np.empty((frames, out_bytes), np.uint8); ret_h = np.empty((frames + G - 1) // G, np.int32)
+            if mode == "registered":  # the caller page-locked its buffers once (dvbs2_host_register)
+                for a in (xh, bits_h, ret_h):
+                    capi.check(capi.lib.dvbs2_host_register(a.ctypes.data, a.nbytes))
+            call = lambda: capi.check(capi.lib.dvbs2_ldpc_decode(d._h, xh.ctypes.data, frames, trials, capi.OM_MESSAGE,
+                                                                 bits_h.ctypes.data, None, ret_h.ctypes.data))
+            call()
+            if shard is not None:
+                shard.barrier_sync()
+            t0 = time.perf_counter()
+            for _ in range(steps2):
+                call()
+            th = (time.perf_counter() - t0) / steps2
+            if shard is not None:
+                shard.barrier_sync()
+            dx = torch.from_numpy(xh).to(dev); db = torch.empty((frames, out_bytes), dtype=torch.uint8, device=dev)
+            fnr = lambda: d.work_device(dx.data_ptr(), frames, db.data_ptr(), 0, 0, stream)
+            fnr(); torch.cuda.synchronize(); t0 = time.perf_counter()
+            for _ in range(steps2):
+                fnr()
+            torch.cuda.synchronize(); tr = (time.perf_counter() - t0) / steps2
+            if not np.array_equal(bits_h, db.cpu().numpy()):
+                raise RuntimeError("PARITY FAILURE: host-buffer entry differs from the device entry")
+            host[f"{frames}_{mode}"] = {"frames_per_call": frames, "frames_per_s": frames / th, "ms_per_call": th * 1e3,
+                                        "resident_frames_per_s": frames / tr, "frac_of_resident": tr / th,
+                                        # bytes the call moves over the link per second of the call (in + out): the rate the decode
+                                        # CONSUMES, not the link's capacity -- that is `host_link`
+                                        "link_gbs_consumed": frames * (N + out_bytes + 4.0 / G) / th / 1e9}
+            if mode == "registered":
+                for a in (xh, bits_h, ret_h):
+                    capi.check(capi.lib.dvbs2_host_unregister(a.ctypes.data))
+            del dx, db
+    fb = d.fallback_rounds
+    d.close()
+    return host, fb
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -305,6 +367,7 @@ def main():
                            "spread": (max(per_rank) - min(per_rank)) / max(per_rank),
                            "note": "each rank's own clock over the same K steps (common start after the barrier, its own last "
                                    "completion); `value` uses the slowest rank's time"}
+    out["fallback_rounds"] = dec.fallback_rounds  # host-driven rounds of the group stop (zero in normal operation)
     dec.close()
     del llr, d_bits
 
@@ -400,7 +463,7 @@ def main():
 
     # ---------------------------------------------------------------- SURVEY 8(d) secondaries of config 2 (one GPU)
     if world == 1 and not args.no_configs and args.input == "noise":
-        extras = [c for c in args.only.split(",") if c] or ["config2_awgn", "config2_host", "device_copy"]
+        extras = [c for c in args.only.split(",") if c] or ["config2_awgn", "config2_host", "device_copy", "host_link", "mapping_ceiling"]
         bl50 = ldpc_bytes(N, out_bytes, info["links_total"], args.trials)
         if "config2_awgn" in extras:
             d = LdpcDecoder(standard=capi.STANDARD_DVBS2, framesize=capi.FECFRAME_NORMAL, rate="C1_2", outputmode=capi.OM_MESSAGE,
@@ -431,47 +494,52 @@ def main():
                 "frac_of_proportional_rate": val / (out["value"] * args.trials / max(mean_upd, 1e-9))}
             d.close(); del x
         if "config2_host" in extras:
-            d = LdpcDecoder(standard=capi.STANDARD_DVBS2, framesize=capi.FECFRAME_NORMAL, rate="C1_2", outputmode=capi.OM_MESSAGE,
-                            max_trials=args.trials, group_size=G, max_frames=nf, device=local)
-            host = {}
-            for frames in (nf, 512):
-                xh = noise_llr(torch, frames, N, dev, 12345).cpu().numpy()
-                for mode in ("pageable", "registered"):
-                    bits_h = np.empty((frames, out_bytes), np.uint8); ret_h = np.empty((frames + G - 1) // G, np.int32)
-                    if mode == "registered":  # the caller page-locked its buffers once (dvbs2_host_register)
-                        for a in (xh, bits_h, ret_h):
-                            capi.check(capi.lib.dvbs2_host_register(a.ctypes.data, a.nbytes))
-                    call = lambda: capi.check(capi.lib.dvbs2_ldpc_decode(d._h, xh.ctypes.data, frames, args.trials, capi.OM_MESSAGE,
-                                                                         bits_h.ctypes.data, None, ret_h.ctypes.data))
-                    call()
-                    t0 = time.perf_counter()
-                    for _ in range(steps2):
-                        call()
-                    th = (time.perf_counter() - t0) / steps2
-                    dx = torch.from_numpy(xh).to(dev); db = torch.empty((frames, out_bytes), dtype=torch.uint8, device=dev)
-                    fnr = lambda: d.work_device(dx.data_ptr(), frames, db.data_ptr(), 0, 0, stream)
-                    fnr(); torch.cuda.synchronize(); t0 = time.perf_counter()
-                    for _ in range(steps2):
-                        fnr()
-                    torch.cuda.synchronize(); tr = (time.perf_counter() - t0) / steps2
-                    if not np.array_equal(bits_h, db.cpu().numpy()):
-                        raise RuntimeError("PARITY FAILURE: host-buffer entry differs from the device entry")
-                    host[f"{frames}_{mode}"] = {"frames_per_call": frames, "frames_per_s": frames / th, "ms_per_call": th * 1e3,
-                                                "resident_frames_per_s": frames / tr, "frac_of_resident": tr / th,
-                                                "pcie_in_gbs": frames * N / th / 1e9}
-                    if mode == "registered":
-                        for a in (xh, bits_h, ret_h):
-                            capi.check(capi.lib.dvbs2_host_unregister(a.ctypes.data))
-                    del dx, db
+            host, fb = host_entry(np, torch, capi, LdpcDecoder, T, dev, local, N, out_bytes, nf, args.trials, G, stream, steps2, (nf, 512))
             configs["config2_host"] = {"workload": "dvbs2_ldpc_decode (host buffers in and out: H2D + decode + D2H per synchronous call), "
                                                    f"table B4, cap {args.trials}, noise LLRs; never the headline value", "unit": "frames/s",
-                                       "value": host[f"{nf}_pageable"]["frames_per_s"], "calls": host,
+                                       "value": host[f"{nf}_pageable"]["frames_per_s"], "calls": host, "fallback_rounds": fb,
                                        "step_frac_of_hbm_peak": bl50 * host[f"{nf}_pageable"]["frames_per_s"] / 1e9 / HBM_PEAK_GBS}
-            d.close()
+        if "host_link" in extras:
+            out["host_link"] = host_link_bandwidth(capi, local)
         if "device_copy" in extras:
             out["device_copy"] = device_copy_bandwidth(torch, dev)
             out["roofline"]["frac_of_measured_copy"] = out["roofline"]["achieved"] / out["device_copy"]["read_plus_write_gbs"]
+        if "mapping_ceiling" in extras:
+            # What THIS thread-per-check-row mapping does when nothing orders the rows: S2X_TABLE_B3 (9/20 normal) is B4's hazard-free
+            # sibling -- the same check degree 7, the same kernel build, 99 layers, no layer with two entries of one group. Its
+            # edge-update rate, measured in this run, projected onto B4's edge count, is the rate B4 would have without its 8 hazard
+            # layers: the ceiling of the mapping, beside the HBM roofline of the algorithm.
+            sib = "S2X_TABLE_B3"
+            ldpc_only("_sib", sib, nf, args.trials, "")
+            sc = configs.pop("_sib")
+            si = ldpc_table_info(sib)
+            eups = sc["value"] * si["links_total"] * args.trials
+            proj = eups / (info["links_total"] * args.trials)
+            out["roofline"]["mapping_ceiling"] = {
+                "hazard_free_sibling": sib, "sibling_kernel": sc["roofline"]["kernel"], "sibling_frames_per_s": sc["value"],
+                "sibling_parity": sc["parity"], "edge_updates_per_s": eups, "projected_frames_per_s": proj,
+                "projected_frac_of_hbm_peak": b_alg * proj / 1e9 / HBM_PEAK_GBS, "value_frac_of_ceiling": out["value"] / proj,
+                "note": "rate of the same kernel build on the hazard-free degree-7 table, per edge update, projected onto B4's edges: "
+                        "what is left between `value` and it are B4's 8 hazard layers (ordered lane chains, DESIGN.md 3.3)"}
         out["configs"] = configs
+
+    if world > 1 and not args.no_configs and args.input == "noise":
+        # the expected limiter of the sharded job is host feeding, not the GPUs. Every rank runs the host-buffer entry
+        # (H2D + decode + D2H per call, call site lib/ldpc_decoder_bb_impl.cc:406-449) at the same time; per-rank and summed rates
+        # beside the resident `value`.
+        host, fb = host_entry(np, torch, capi, LdpcDecoder, T, dev, local, N, out_bytes, nf, args.trials, G, stream, steps2, (nf,), shard)
+        feed = {}
+        for mode in ("pageable", "registered"):
+            per = shard.gather_over_ranks(host[f"{nf}_{mode}"]["frames_per_s"], device=dev)
+            res = shard.gather_over_ranks(host[f"{nf}_{mode}"]["resident_frames_per_s"], device=dev)
+            feed[mode] = {"per_rank_frames_per_s": per, "sum_frames_per_s": sum(per), "sum_resident_frames_per_s": sum(res),
+                          "frac_of_resident": sum(per) / max(sum(res), 1e-9),
+                          "link_gbs_consumed_sum": sum(per) * (N + out_bytes + 4.0 / G) / 1e9}
+        fbs = shard.gather_over_ranks(float(fb), device=dev)
+        out.setdefault("configs", {})["config2_host"] = {
+            "workload": f"dvbs2_ldpc_decode from host buffers on all {world} ranks at once ({nf}-frame synchronous calls, table B4, cap "
+                        f"{args.trials}, noise LLRs): the host feed of the sharded job; never the headline value",
+            "unit": "frames/s", "value": feed["pageable"]["sum_frames_per_s"], "ranks": feed, "fallback_rounds": sum(fbs)}
 
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:

@@ -1,9 +1,12 @@
 // c_api.hip -- extern "C" boundary (include/dvbs2_fec_hip.h). No exceptions leave this file.
 #include "../../include/dvbs2_fec_hip.h"
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
+#include <utility>
+#include <vector>
 #include "fec_tables.h"
 #include "ldpc_hip.h"
 #include "ldpc_schedule.h"
@@ -33,6 +36,11 @@ struct dvbs2_ldpc {
     // the chunk's kernels are done, which would serialise the chunks
     uint8_t* p_bits = nullptr; int8_t* p_llr = nullptr; int32_t* p_ret = nullptr;
     hipStream_t stream[LdpcDecoderHip::kSlots] = {};
+    // inputs go through ONE copy stream, chunk after chunk (each copy at the full link rate, chunk 0 first), and the chunk's compute
+    // stream waits for its event: with the copies on the four compute streams a page-locked caller's chunks 0..3 shared the link and
+    // the first kernel started after FOUR chunks had arrived instead of one (round 3: page-locked callers 8 % slower than pageable ones)
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t in_ready[LdpcDecoderHip::kSlots] = {};
     int device = 0;
 };
 
@@ -162,6 +170,8 @@ void dvbs2_ldpc_destroy(dvbs2_ldpc_t* h)
     if (h->p_llr) (void)hipHostFree(h->p_llr);
     if (h->p_ret) (void)hipHostFree(h->p_ret);
     for (hipStream_t st : h->stream) if (st) (void)hipStreamDestroy(st);
+    if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
+    for (hipEvent_t ev : h->in_ready) if (ev) (void)hipEventDestroy(ev);
     delete h->dec;
     delete h;
 }
@@ -226,6 +236,8 @@ int dvbs2_ldpc_decode(dvbs2_ldpc_t* h, const int8_t* llr_in, int n_frames, int m
     const size_t N = h->dec->N(), mf = h->dec->max_frames();
     const int G = h->dec->group_size();
     for (hipStream_t& st : h->stream) if (!st) HCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    if (!h->copy_stream) HCHK(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+    for (hipEvent_t& ev : h->in_ready) if (!ev) HCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     if (!h->d_in) HCHK(hipMalloc(&h->d_in, mf * N));
     if (!h->d_bits) HCHK(hipMalloc(&h->d_bits, mf * (N / 8)));
     if (!h->d_llr) HCHK(hipMalloc(&h->d_llr, mf * N));
@@ -234,6 +246,8 @@ int dvbs2_ldpc_decode(dvbs2_ldpc_t* h, const int8_t* llr_in, int n_frames, int m
     // Results land where the DMA engine can write them: straight in the caller's buffer when it is page-locked (hipHostMalloc'ed, or
     // registered once with dvbs2_host_register -- what a block does with its item buffers), else in a pinned buffer of the handle
     // that is copied out when the chunk has finished.
+    // (the WHOLE range has to be one page-locked allocation / registration: first and last byte page-locked is not enough when two
+    // registrations leave a pageable hole between them -- the range of the allocation that holds the first byte must cover the last)
     auto page_locked = [](const void* p, size_t bytes) {
         if (!p || !bytes) return false;
         hipPointerAttribute_t a0{}, a1{};
@@ -241,7 +255,12 @@ int dvbs2_ldpc_decode(dvbs2_ldpc_t* h, const int8_t* llr_in, int n_frames, int m
             (void)hipGetLastError(); // an ordinary pageable pointer: not an error of this call
             return false;
         }
-        return a0.type == hipMemoryTypeHost && a1.type == hipMemoryTypeHost;
+        if (a0.type != hipMemoryTypeHost || a1.type != hipMemoryTypeHost) return false;
+        // one registration / allocation maps to one contiguous range of device addresses: the two ends must be bytes - 1 apart there too
+        // (two registrations with a pageable hole between them are two unrelated mappings)
+        if (a0.devicePointer && a1.devicePointer)
+            return (size_t)((const char*)a1.devicePointer - (const char*)a0.devicePointer) == bytes - 1;
+        return true;
     };
     const size_t n_groups = ((size_t)n_frames + G - 1) / G;
     uint8_t* bits_land = page_locked(bits_out, (size_t)n_frames * out_bytes) ? bits_out : nullptr;
@@ -250,17 +269,45 @@ int dvbs2_ldpc_decode(dvbs2_ldpc_t* h, const int8_t* llr_in, int n_frames, int m
     if (!bits_land) { if (!h->p_bits) HCHK(hipHostMalloc(&h->p_bits, mf * (N / 8))); bits_land = h->p_bits; }
     if (ret && !ret_land) { if (!h->p_ret) HCHK(hipHostMalloc(&h->p_ret, ((mf + G - 1) / G + LdpcDecoderHip::kSlots) * 4)); ret_land = h->p_ret; }
     if (llr_out && !llr_land) { if (!h->p_llr) HCHK(hipHostMalloc(&h->p_llr, mf * N)); llr_land = h->p_llr; }
-    // Chunks of whole groups (an even number of frames: two frames per workgroup) of at least 512 frames -- one frame pair
-    // per CU; a smaller launch takes just as long -- and about an eighth of the call: the host-to-device copy of chunk
-    // c + 1 and the device-to-host copies of chunk c - 1 run under the decode of chunk c. Chunk c uses slot and stream
-    // c % kSlots (its own range of the state and message buffers).
+    // The call is cut into chunks of whole groups (an even number of frames: two frames per workgroup); chunk c uses slot and stream
+    // c % kSlots (its own range of the state and message buffers), so that transfers and decodes of neighbouring chunks overlap.
     int unit = G % 2 ? 2 * G : G;
-    int chunk = std::max(512, (n_frames + 7) / 8);
-    if (const char* e = getenv("DVBS2_HOST_CHUNK")) chunk = std::max(2, atoi(e)); // experiments
-    chunk = (chunk + unit - 1) / unit * unit;
-    const int n_chunks = (n_frames + chunk - 1) / chunk;
+    const bool in_locked = page_locked(llr_in, (size_t)n_frames * N);
+    // Plan of the call, as (first frame, frames) chunks of whole groups. The decode of a chunk starts when its input has arrived and a
+    // launch of up to 512 frames (one frame pair per CU) takes as long as a smaller one, so the FIRST chunk is 512 frames; every further
+    // chunk boundary costs a launch gap that the single resident launch does not have. Pageable input: the runtime stages the copy
+    // through its own pinned buffer while the calling thread waits, so the copy of chunk c + 1 has to run under the decode of chunk c:
+    // chunks of 1024. Page-locked input (dvbs2_host_register / hipHostMalloc): the link moves 57 GB/s (bench.py host_link), the whole
+    // input of 4096 normal frames arrives in under 5 ms through the copy stream: one large middle chunk, and a small last one so that
+    // little output is left to fetch when the decode ends.
+    std::vector<std::pair<int, int>> plan;
+    auto round_unit = [&](int x) { return std::max(unit, (x + unit - 1) / unit * unit); };
+    if (const char* e = getenv("DVBS2_HOST_PLAN")) { // experiments: comma list of chunk sizes, the last one repeats
+        int f0 = 0, last = 512;
+        for (const char* q = e; f0 < n_frames;) {
+            if (*q) { last = std::max(2, atoi(q)); while (*q && *q != ',') q++; if (*q == ',') q++; }
+            const int nf = std::min(round_unit(last), n_frames - f0);
+            plan.push_back({ f0, nf }); f0 += nf;
+        }
+    } else if (in_locked && n_frames > 1024 && !getenv("DVBS2_HOST_CHUNK")) {
+        // measured (MI355X, 4096 frames of table B4, tools/host_entry_ab.py): 512 | 3072 | 512 -> 97.3 % of the resident rate, 512 | 3584
+        // 97.3 %, 512 | 1536 | 1536 | 512 96.7 %, eight chunks of 512 93.6 %, four of 1024 95.0 %
+        const int b1 = round_unit(512);                                   // every boundary is a multiple of `unit` (frame_base of enqueue())
+        const int b2 = std::max(b1, (n_frames - 512) / unit * unit);
+        const int bounds[4] = { 0, b1, b2, n_frames };
+        for (int k = 0; k < 3; k++) if (bounds[k + 1] > bounds[k]) plan.push_back({ bounds[k], bounds[k + 1] - bounds[k] });
+    } else {
+        // pageable input (measured as above): 512, then chunks of 1024 -> 96.0-96.5 %; eight equal chunks of 512 95.0-95.4 %
+        int first = 512, chunk = std::max(1024, (n_frames + 7) / 8);
+        if (const char* e = getenv("DVBS2_HOST_CHUNK")) first = chunk = std::max(2, atoi(e)); // experiments, tests
+        first = round_unit(first); chunk = round_unit(chunk);
+        for (int f0 = 0; f0 < n_frames;) { const int nf = std::min(f0 ? chunk : first, n_frames - f0); plan.push_back({ f0, nf }); f0 += nf; }
+    }
+    const int n_chunks = (int)plan.size();
+    bool use_copy_stream = in_locked;
+    if (const char* e = getenv("DVBS2_HOST_COPY_STREAM")) use_copy_stream = atoi(e) != 0; // experiments
     auto copy_out = [&](int c) -> int {
-        const int f0 = c * chunk, nf = std::min(chunk, n_frames - f0);
+        const int f0 = plan[c].first, nf = plan[c].second;
         hipStream_t st = h->stream[c % LdpcDecoderHip::kSlots];
         HCHK(hipMemcpyAsync(bits_land + (size_t)f0 * out_bytes, h->d_bits + (size_t)f0 * out_bytes, (size_t)nf * out_bytes, hipMemcpyDeviceToHost, st));
         if (llr_out) HCHK(hipMemcpyAsync(llr_land + (size_t)f0 * N, h->d_llr + (size_t)f0 * N, (size_t)nf * N, hipMemcpyDeviceToHost, st));
@@ -272,7 +319,7 @@ int dvbs2_ldpc_decode(dvbs2_ldpc_t* h, const int8_t* llr_in, int n_frames, int m
         if (r < 0) return fail(DVBS2_EDEVICE, h->dec->error());
         if (r > 0) { if (int rc = copy_out(c)) return rc; } // outputs rewritten by the extra rounds: fetch them again
         HCHK(hipStreamSynchronize(h->stream[c % LdpcDecoderHip::kSlots]));
-        const int f0 = c * chunk, nf = std::min(chunk, n_frames - f0);
+        const int f0 = plan[c].first, nf = plan[c].second;
         if (bits_land != bits_out) std::memcpy(bits_out + (size_t)f0 * out_bytes, bits_land + (size_t)f0 * out_bytes, (size_t)nf * out_bytes);
         if (llr_out && llr_land != llr_out) std::memcpy(llr_out + (size_t)f0 * N, llr_land + (size_t)f0 * N, (size_t)nf * N);
         if (ret && ret_land != ret) std::memcpy(ret + f0 / G, ret_land + f0 / G, (size_t)((nf + G - 1) / G) * 4);
@@ -282,9 +329,14 @@ int dvbs2_ldpc_decode(dvbs2_ldpc_t* h, const int8_t* llr_in, int n_frames, int m
     auto run = [&]() -> int {
         for (int c = 0; c < n_chunks; c++) {
             if (c >= LdpcDecoderHip::kSlots) if (int rc = finish(c - LdpcDecoderHip::kSlots)) return rc;
-            const int f0 = c * chunk, nf = std::min(chunk, n_frames - f0);
+            const int f0 = plan[c].first, nf = plan[c].second;
             hipStream_t st = h->stream[c % LdpcDecoderHip::kSlots];
-            HCHK(hipMemcpyAsync(h->d_in + (size_t)f0 * N, llr_in + (size_t)f0 * N, (size_t)nf * N, hipMemcpyHostToDevice, st));
+            if (use_copy_stream) {
+                HCHK(hipMemcpyAsync(h->d_in + (size_t)f0 * N, llr_in + (size_t)f0 * N, (size_t)nf * N, hipMemcpyHostToDevice, h->copy_stream));
+                HCHK(hipEventRecord(h->in_ready[c % LdpcDecoderHip::kSlots], h->copy_stream));
+                HCHK(hipStreamWaitEvent(st, h->in_ready[c % LdpcDecoderHip::kSlots], 0));
+            } else
+                HCHK(hipMemcpyAsync(h->d_in + (size_t)f0 * N, llr_in + (size_t)f0 * N, (size_t)nf * N, hipMemcpyHostToDevice, st));
             if (h->dec->enqueue(h->d_in + (size_t)f0 * N, nf, max_trials, out_mode, h->d_bits + (size_t)f0 * out_bytes,
                                 llr_out ? h->d_llr + (size_t)f0 * N : nullptr, h->d_ret + f0 / G, st, c % LdpcDecoderHip::kSlots, f0))
                 return fail(DVBS2_EDEVICE, h->dec->error());
@@ -294,7 +346,11 @@ int dvbs2_ldpc_decode(dvbs2_ldpc_t* h, const int8_t* llr_in, int n_frames, int m
         return DVBS2_OK;
     };
     const int rc = run();
-    if (rc != DVBS2_OK) h->dec->abort_all();
+    if (rc != DVBS2_OK) { // nothing of this call stays in flight (copies into the caller's buffers included)
+        h->dec->abort_all();
+        (void)hipStreamSynchronize(h->copy_stream);
+        for (hipStream_t st : h->stream) (void)hipStreamSynchronize(st);
+    }
     return rc;
     API_CATCH
 }
@@ -302,6 +358,65 @@ int dvbs2_ldpc_decode(dvbs2_ldpc_t* h, const int8_t* llr_in, int n_frames, int m
 const char* dvbs2_ldpc_kernel_name(const dvbs2_ldpc_t* h)
 {
     return h ? h->dec->kernel_name() : nullptr;
+}
+
+int dvbs2_ldpc_fallback_rounds(const dvbs2_ldpc_t* h)
+{
+    return h ? h->dec->fallback_rounds() : -1;
+}
+
+int dvbs2_measure_host_copy(int device, size_t bytes, int n_streams, int kind, double* h2d_gbs, double* d2h_gbs)
+{
+    API_TRY
+    if (!bytes || n_streams < 1 || n_streams > 16 || kind < 0 || kind > 2) return fail(DVBS2_EINVAL, "bad argument");
+    DeviceGuard guard(device);
+    if (!guard.ok) return fail(DVBS2_EDEVICE, "hipSetDevice failed");
+    void* host = nullptr; void* dev = nullptr;
+    hipStream_t st[16] = {};
+    hipEvent_t e0 = nullptr, e1 = nullptr, done[16] = {};
+    int rc = DVBS2_OK;
+    auto body = [&]() -> int {
+        if (kind == 0) HCHK(hipHostMalloc(&host, bytes));
+        else {
+            host = std::malloc(bytes);
+            if (!host) return fail(DVBS2_EDEVICE, "out of host memory");
+            std::memset(host, 1, bytes);
+            if (kind == 1) HCHK(hipHostRegister(host, bytes, hipHostRegisterDefault));
+        }
+        HCHK(hipMalloc(&dev, bytes));
+        for (int i = 0; i < n_streams; i++) { HCHK(hipStreamCreateWithFlags(&st[i], hipStreamNonBlocking)); HCHK(hipEventCreateWithFlags(&done[i], hipEventDisableTiming)); }
+        HCHK(hipEventCreate(&e0)); HCHK(hipEventCreate(&e1));
+        const size_t part = (bytes / n_streams) & ~(size_t)4095;
+        for (int dir = 0; dir < 2; dir++) {
+            double best = 0;
+            for (int rep = 0; rep < 3; rep++) { // first repetition warms the path
+                HCHK(hipDeviceSynchronize());
+                HCHK(hipEventRecord(e0, st[0]));
+                for (int i = 1; i < n_streams; i++) HCHK(hipStreamWaitEvent(st[i], e0, 0));
+                for (int i = 0; i < n_streams; i++) {
+                    char* hp = (char*)host + (size_t)i * part; char* dp = (char*)dev + (size_t)i * part;
+                    if (dir == 0) HCHK(hipMemcpyAsync(dp, hp, part, hipMemcpyHostToDevice, st[i]));
+                    else HCHK(hipMemcpyAsync(hp, dp, part, hipMemcpyDeviceToHost, st[i]));
+                    if (i) { HCHK(hipEventRecord(done[i], st[i])); HCHK(hipStreamWaitEvent(st[0], done[i], 0)); }
+                }
+                HCHK(hipEventRecord(e1, st[0]));
+                HCHK(hipEventSynchronize(e1));
+                float ms = 0; HCHK(hipEventElapsedTime(&ms, e0, e1));
+                if (rep && ms > 0) best = std::max(best, (double)part * n_streams / (ms * 1e-3) / 1e9);
+            }
+            if (dir == 0) { if (h2d_gbs) *h2d_gbs = best; } else if (d2h_gbs) *d2h_gbs = best;
+        }
+        return DVBS2_OK;
+    };
+    rc = body();
+    (void)hipDeviceSynchronize();
+    for (int i = 0; i < n_streams; i++) { if (st[i]) (void)hipStreamDestroy(st[i]); if (done[i]) (void)hipEventDestroy(done[i]); }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (dev) (void)hipFree(dev);
+    if (host) { if (kind == 0) (void)hipHostFree(host); else { if (kind == 1) (void)hipHostUnregister(host); std::free(host); } }
+    return rc;
+    API_CATCH
 }
 
 int dvbs2_ldpc_profile(dvbs2_ldpc_t* h, int enable, double* total_ms, int* launches)

@@ -66,6 +66,9 @@ public:
     void reset_profile() { prof_ms_ = 0; prof_launches_ = 0; }
     double profile_ms() const { return prof_ms_; }
     int profile_launches() const { return prof_launches_; }
+    // host-driven resolution rounds since the handle was created (finish(): a waiting frame of the group-synchronous stop gave up
+    // and the group was completed by resume launches): zero in normal operation, asserted by the tests and printed by bench.py
+    int fallback_rounds() const { return fallback_rounds_; }
 
 private:
     LdpcSchedule sched_;
@@ -80,6 +83,8 @@ private:
     bool v2_ = false;             // the build with the packed nodes (check_node_v2 / check_node_chain_v2)
     bool chain_plain_ = false;    // plain sweep kernel with the packed register chain for single-pair hazard layers
     bool soft_bar_ = false;       // per-frame software barriers (high-degree tables without hazard layers)
+    int fallback_rounds_ = 0;
+    bool sticky_pretest_ = true;  // the syndrome pre-test re-tests the layer in which the last full test failed (ldpc_kernel.hpp; bit 3 of the flag word turns it off)
     bool pr_w1_ = false;          // parity-in-records kernel with one-dword records (check degree <= 4)
     bool hz2_ = false;            // the build with the heavy-hazard paths (ldpc_kernel.hpp, HZ2)
     bool solo_ = false;           // one frame per workgroup, complementary wave roles per CU (ldpc_kernel.hpp)

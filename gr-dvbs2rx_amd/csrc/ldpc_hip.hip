@@ -352,6 +352,7 @@ LdpcDecoderHip::LdpcDecoderHip(const LdpcTableDesc* table, int out_bits_message,
         const uint32_t hd[kRecHeaderWords] = { (uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32), (uint32_t)G_, (uint32_t)spin_max, 0, 0 };
         HIP_OK(hipMemcpy(d_recs_alloc_, hd, sizeof(hd), hipMemcpyHostToDevice));
     }
+    if (const char* e = getenv("DVBS2_STICKY_PRETEST")) sticky_pretest_ = atoi(e) != 0; // experiments: 0 = always pre-test layer `it mod q` (rounds 1-3)
     if (const char* e = getenv("DVBS2_RESOLVE_ROUNDS")) resolve_rounds_ = std::max(0, std::min(8, atoi(e))); // tests: 0 forces the host-side leftover path
     HIP_OK(hipMalloc(&d_flag_, 4 * kSlots));
     HIP_OK(hipHostMalloc(&h_flag_, 4 * kSlots));
@@ -398,7 +399,7 @@ void LdpcDecoderHip::launch_sweep(const int8_t* in, bool resume, int stop_on_goo
     la.iters = d_iters_ + fb; la.good = d_good_ + fb; la.target = resume ? d_target_ + fb : nullptr;
     const bool gs = gsync_on_ && !resume && stop_on_good; // group-synchronous stop: bit 2 of the flag word; its words start from zero
     if (gs) (void)hipMemsetAsync(d_gsync_ + 2 * (size_t)(frame_base / G_), 0, (size_t)((n_frames + G_ - 1) / G_) * 8, stream); // (frame_base is a multiple of the group size: enqueue())
-    la.n_frames = n_frames; la.N = sched_.N; la.K = sched_.K; la.q = sched_.q; la.cap = max_trials; la.stop_on_good = stop_on_good | (soft_bar_ ? 2 : 0) | (gs ? 4 : 0);
+    la.n_frames = n_frames; la.N = sched_.N; la.K = sched_.K; la.q = sched_.q; la.cap = max_trials; la.stop_on_good = stop_on_good | (soft_bar_ ? 2 : 0) | (gs ? 4 : 0) | (sticky_pretest_ ? 0 : 8);
     la.tdbg = d_tdbg_; la.lds_bytes = solo_ ? half_lds_bytes(sched_.N) : lds_bytes_; la.stream = stream; la.dense = dense_;
     la.v2 = pr_ ? pr_w1_ : v2_; la.solo = solo_; la.chain = chain_plain_; la.hz2 = hz2_; la.soft = soft_bar_; la.cu_slots = d_cu_slots_;
     la.dm = DemapFused{};
@@ -448,7 +449,8 @@ int LdpcDecoderHip::enqueue(const int8_t* d_llr_in, int n_frames, int max_trials
     if (max_trials < 0) { call_err_ = "max_trials < 0"; return -1; }
     Pending& p = pend_[slot];
     // a call that fails below leaves the slot free again (the handle stays usable: "a failed call does not disable the handle")
-    struct Release { Pending& p; bool armed = true; ~Release() { if (armed) p.active = false; } } release{ p };
+    // (and nothing of it stays in flight: kernels and copies already queued on the stream are waited for before the slot is given up)
+    struct Release { Pending& p; bool armed = true, launched = false; ~Release() { if (armed) { if (launched) (void)hipStreamSynchronize(p.stream); p.active = false; } } } release{ p };
     p.active = true; p.n_frames = n_frames; p.max_trials = max_trials; p.out_mode = out_mode; p.frame_base = frame_base;
     p.bits = d_bits_out; p.llr_out = d_llr_out; p.ret = d_ret; p.stream = stream;
     h_flag_[slot] = 0;
@@ -456,6 +458,7 @@ int LdpcDecoderHip::enqueue(const int8_t* d_llr_in, int n_frames, int max_trials
     DeviceGuard dev_guard(device_);
     if (!dev_guard.ok) { call_err_ = "hipSetDevice failed"; return -1; }
     if (dm && dm->mode && pr_) { call_err_ = "this sweep kernel does not demap while loading"; return -1; }
+    release.launched = true;
     launch_sweep(d_llr_in, false, 1, n_frames, max_trials, frame_base, stream, dm);
     if (d_tdbg_) {
         HIP_RET(hipStreamSynchronize(stream));
@@ -515,8 +518,10 @@ int LdpcDecoderHip::finish(int slot)
     if (!dev_guard.ok) { call_err_ = "hipSetDevice failed"; return -1; }
     HIP_RET(hipStreamSynchronize(p.stream));
     if (h_flag_[slot] == 0) return 0;
+    struct Drain { hipStream_t st; bool armed = true; ~Drain() { if (armed) (void)hipStreamSynchronize(st); } } drain{ p.stream }; // a failing round leaves nothing in flight
     for (int round = 0; h_flag_[slot] != 0; round++) { // the rare leftovers, one host round trip each
         if (round > 2 * p.max_trials + 2) { call_err_ = "group resolution did not converge"; return -1; }
+        fallback_rounds_++;
         launch_sweep(nullptr, true, 0, p.n_frames, p.max_trials, p.frame_base, p.stream);
         launch_targets(p.n_frames, p.max_trials, p.frame_base, p.ret, slot, p.stream);
         HIP_RET(hipMemcpyAsync(h_flag_ + slot, d_flag_ + slot, 4, hipMemcpyDeviceToHost, p.stream));
@@ -525,6 +530,7 @@ int LdpcDecoderHip::finish(int slot)
     launch_finalize(p);
     HIP_RET(hipGetLastError());
     HIP_RET(hipStreamSynchronize(p.stream));
+    drain.armed = false;
     return 1; // outputs were rewritten after the stream's first completion
 }
 

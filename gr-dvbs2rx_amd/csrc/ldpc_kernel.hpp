@@ -1255,7 +1255,7 @@ __global__ __launch_bounds__(SOLO ? kSoloThreads : kThreads, SOLO ? 4 : MINW) vo
     const uint32_t* __restrict__ recs, const uint32_t* __restrict__ wrecs /*per (layer, wave) sweep records*/,
     const int8_t* __restrict__ llr_in, uint8_t* __restrict__ state,
     uint32_t* __restrict__ msgs, int* __restrict__ iters, int* __restrict__ good, const int* __restrict__ target,
-    int n_frames, int N, int K, int q, int cap, int stop_on_good /*bit 0: stop at a good syndrome, bit 1: software frame barriers, bit 2: group-synchronous stop*/,
+    int n_frames, int N, int K, int q, int cap, int stop_on_good /*bit 0: stop at a good syndrome, bit 1: software frame barriers, bit 2: group-synchronous stop, bit 3: pre-test always on layer it mod q*/,
     unsigned long long* __restrict__ tdbg, int* __restrict__ cu_slots,
     const DemapFused dm /*mode != 0: a fresh decode takes XFECFRAME symbols and demaps while loading (llr_in is null then)*/)
 {
@@ -1383,7 +1383,7 @@ __global__ __launch_bounds__(SOLO ? kSoloThreads : kThreads, SOLO ? 4 : MINW) vo
         }
     }
     const bool untouched = finished; // never loaded: must not write state/iters/good back
-    if (tid == 0) { flags[0] = 0; flags[2] = 0; flags[3] = 0; flags[1] = finished ? 1 : 0; flags[4] = 0; }
+    if (tid == 0) { flags[0] = 0; flags[2] = 0; flags[3] = 0; flags[1] = finished ? 1 : 0; flags[4] = 0; flags[5] = 0; }
     // Frame barriers in software (bit 1 of the flag word; pair workgroups only): worth it for high-degree tables without hazard
     // layers -- few barriers, long layers: S2X B21 +12 %, S2X B10 +10 % -- and a loss where barriers are frequent (B4 -8 %: the
     // counter costs ~300 cycles per barrier against ~30 for s_barrier). Chosen per table by the host.
@@ -1447,8 +1447,13 @@ __global__ __launch_bounds__(SOLO ? kSoloThreads : kThreads, SOLO ? 4 : MINW) vo
         const bool need_synd = !finished && ((stop_on_good & 1) || it >= tgt);
         // Pre-test (the reference's bad() also returns at the first failing check): the 360 checks of ONE layer,
         // tested edge by edge. A failure here is final; only a frame that passes pays for the full test below.
+        // WHICH layer is pre-tested is free (any failing check makes the batch bad; a pass is followed by the full test): round 4 keeps
+        // the layer in which the last full test found an unsatisfied check (flags[5] = layer + 1) -- near convergence the few wrong bits
+        // keep the same checks unsatisfied for several updates, so a frame pays for a full test only when that layer has become clean
+        // (operating point: most updates of a converging frame used to run the full test), and falls back to layer `it mod q`.
         if (need_synd && active) {
-            const int i0 = it % q;
+            const int hint = (stop_on_good & 8) ? 0 : flags[5];
+            const int i0 = hint ? hint - 1 : it % q;
             const uint32_t* rec = recs + (size_t)i0 * RS;
             const int deg = (int)(rec[0] & 0xffu) + 2;
             uint32_t x = 0, z = 0;
@@ -1514,7 +1519,7 @@ __global__ __launch_bounds__(SOLO ? kSoloThreads : kThreads, SOLO ? 4 : MINW) vo
                     }
                 }
                 if (w == 11) acc &= 0xffu;
-                bad |= acc != 0;
+                if (acc != 0) { bad = 1; flags[5] = i + 1; } // (any failing layer will do as the next pre-test: a benign race)
             }
             if (__ballot(bad) != 0 && lane == 0) flags[0] = 1;
         }

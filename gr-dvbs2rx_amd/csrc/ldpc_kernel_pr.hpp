@@ -118,7 +118,7 @@ template <bool W1>
 __global__ __launch_bounds__(kThreads, 6) void ldpc_layered_pr_kernel(
     const uint32_t* __restrict__ recs, const int8_t* __restrict__ llr_in, uint8_t* __restrict__ state,
     uint32_t* __restrict__ msgs, int* __restrict__ iters, int* __restrict__ good, const int* __restrict__ target,
-    int n_frames, int N, int K, int q, int cap, int stop_on_good /*bit 0: stop at a good syndrome, bit 2: group-synchronous stop (ldpc_kernel.hpp, group_decide)*/)
+    int n_frames, int N, int K, int q, int cap, int stop_on_good /*bit 0: stop at a good syndrome, bit 2: group-synchronous stop (ldpc_kernel.hpp, group_decide), bit 3: pre-test always on layer it mod q*/)
 {
     if (!llr_in) { // resume launch: a workgroup whose frames are both at their target leaves before touching LDS
         const int fa = 2 * (int)blockIdx.x, fb = fa + 1;
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(kThreads, 6) void ldpc_layered_pr_kernel(
         }
     }
     const bool untouched = finished;
-    if (tid == 0) { flags[0] = 0; flags[2] = 0; flags[3] = 0; flags[1] = finished ? 1 : 0; }
+    if (tid == 0) { flags[0] = 0; flags[2] = 0; flags[3] = 0; flags[1] = finished ? 1 : 0; flags[5] = 0; }
     __syncthreads();
 
     bool is_good = false;
@@ -198,7 +198,8 @@ __global__ __launch_bounds__(kThreads, 6) void ldpc_layered_pr_kernel(
         // ---- syndrome test: pre-test on one layer, full test only for frames that pass it (see ldpc_kernel.hpp) ----
         const bool need_synd = !finished && ((stop_on_good & 1) || it >= tgt);
         if (need_synd && active) {
-            const int i0 = it % q;
+            const int hint = (stop_on_good & 8) ? 0 : flags[5]; // layer + 1 in which the last full test found an unsatisfied check (ldpc_kernel.hpp)
+            const int i0 = hint ? hint - 1 : it % q;
             const uint32_t* rec = recs + (size_t)i0 * RS;
             const int deg = (int)(rec[0] & 0xffu) + 2;
             uint32_t x = 0, z = 0;
@@ -267,7 +268,7 @@ __global__ __launch_bounds__(kThreads, 6) void ldpc_layered_pr_kernel(
                             acc ^= x;
                         }
                         if (w == 11) acc &= 0xffu;
-                        bad |= acc != 0;
+                        if (acc != 0) { bad = 1; flags[5] = i + 1; }
                     }
                     if (__ballot(bad) != 0 && lane == 0) flags[0] = 1;
                 }

@@ -152,6 +152,11 @@ class LdpcDecoder:
         check(lib.dvbs2_ldpc_profile(self._h, 1 if enable else 0, ms, n))
         return ms.value, n.value
 
+    @property
+    def fallback_rounds(self):
+        """host-driven resolution rounds of the group stop since creation (zero in normal operation)"""
+        return lib.dvbs2_ldpc_fallback_rounds(self._h)
+
 
 class BchDecoder:
     """bch_decoder_bb's compute (reference lib/bch_decoder_bb_impl.cc:84-117): n/8-byte codewords -> k/8-byte messages."""

@@ -53,7 +53,11 @@ int dvbs2_device_count(void);
  * Radio input buffer, once, at start() -- so that the transfers run at PCIe speed and asynchronously (pageable memory
  * goes through a staging copy at a fraction of it and blocks the calling thread). Optional; undo before freeing.
  * dvbs2_ldpc_decode() also lands its results directly in bits_out / llr_out / ret when THOSE are page-locked (registered here or
- * allocated with hipHostMalloc) instead of in pinned buffers of the handle that it copies out afterwards. */
+ * allocated with hipHostMalloc) instead of in pinned buffers of the handle that it copies out afterwards -- the WHOLE output range has
+ * to lie inside ONE registration / allocation visible to the handle's device (a range that spans two registrations with a pageable
+ * hole, or any range the runtime cannot vouch for, goes through the handle's pinned buffers: slower, never wrong).
+ * Device pointers handed to the *_device entry points: d_llr_in and d_llr_out are accessed with 8-byte loads / stores (align them
+ * to 8 bytes: hipMalloc'ed buffers and whole-frame offsets into them are, N is a multiple of 8). */
 int dvbs2_host_register(void* p, size_t bytes);
 int dvbs2_host_unregister(void* p);
 
@@ -122,6 +126,15 @@ int dvbs2_ldpc_finish(dvbs2_ldpc_t* h);
 /* HIP-event timing of the dominant kernel (the layered update sweep) on its launch stream.
  * enable != 0 starts/reset accumulation; reads back total milliseconds and launch count. */
 int dvbs2_ldpc_profile(dvbs2_ldpc_t* h, int enable, double* total_ms, int* launches);
+/* Diagnostics. Host-driven resolution rounds since the handle was created: the group-synchronous stopping rule is resolved inside
+ * the first launch; a frame that waited longer than the give-up threshold for its group makes finish() complete the group with resume
+ * launches (results identical). Zero in normal operation -- tests and bench.py assert it. */
+int dvbs2_ldpc_fallback_rounds(const dvbs2_ldpc_t* h);
+/* Diagnostics. Plain hipMemcpyAsync rate of this box's host link, GB/s, best of two timed repetitions: `bytes` split evenly over
+ * n_streams (1..16) concurrent streams, host memory kind 0 = hipHostMalloc, 1 = malloc + hipHostRegister (what dvbs2_host_register
+ * does to a caller's buffer), 2 = pageable malloc. Beside the host-entry rates of bench.py (config2_host): is the link or the
+ * pipeline what limits dvbs2_ldpc_decode? (reference call site that hands over host buffers: lib/ldpc_decoder_bb_impl.cc:406-449) */
+int dvbs2_measure_host_copy(int device, size_t bytes, int n_streams, int kind, double* h2d_gbs, double* d2h_gbs);
 /* which sweep kernel the handle launches, as rocprofv3 names it: "ldpc_layered_kernel<DMAX>" or
  * "ldpc_layered_pr_kernel" (parity LLRs kept in registers / message records; chosen per table, identical results) */
 const char* dvbs2_ldpc_kernel_name(const dvbs2_ldpc_t* h);

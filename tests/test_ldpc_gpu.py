@@ -532,3 +532,49 @@ def test_group_stop_fallback_when_members_give_up(monkeypatch, table, amp, sigma
         r32 = compare(table, llr, 32, 50)
         compare(table, llr[:80], 16, 30)
         assert len(set(r32.tolist())) > 1
+
+
+@pytest.mark.parametrize("table,amp,sigma", [("S2_TABLE_B4", 6, 5.2), ("S2_TABLE_C1", 5, 6.5), ("S2_TABLE_B7", 8, 3.6)])
+@pytest.mark.parametrize("sticky", ["1", "0"])
+def test_syndrome_pretest_layer_choice(monkeypatch, table, amp, sigma, sticky):
+    """Round 4: the syndrome pre-test re-tests the layer in which the last full test found an unsatisfied check instead of layer
+    `it mod q` (csrc/ldpc_kernel.hpp). Which layer is pre-tested must not show in any output: frames that converge at different
+    counts, one that never does and one clean codeword, against the reference, with the choice on and off."""
+    monkeypatch.setenv("DVBS2_STICKY_PRETEST", sticky)
+    llr, _ = T.llr_codeword_awgn(table, 96, 4321, amp=amp, sigma=sigma)
+    llr[5] = T.llr_noise(1, llr.shape[1], 8)[0]
+    llr[40] = T.llr_codeword_awgn(table, 1, 7, amp=20, sigma=0.0)[0][0]
+    r = compare(table, llr, 32, 50)
+    assert len(set(r.tolist())) > 1
+    compare(table, llr[:48], 16, 50)
+
+
+def test_group_stop_needs_no_host_round_at_the_default_threshold():
+    """a member that gives up waiting for its group is repaired by host-driven rounds (finish()); at the default
+    give-up threshold that must not happen -- the library counts those rounds (dvbs2_ldpc_fallback_rounds) and a converging batch of
+    the headline table, decoded several times through the device and the chunked host entry, must leave the counter at zero."""
+    table = "S2_TABLE_B4"
+    N, K, _, _ = T.ldpc_info(table)
+    llr, _ = T.llr_codeword_awgn(table, 1024, 77, amp=6, sigma=4.8)
+    dec = LdpcDecoder(table=table, message_bits=K, group_size=32, max_frames=1024, max_trials=50, outputmode=capi.OM_MESSAGE)
+    want = None
+    for _ in range(4):
+        bits, _, ret = dec.work(llr, want_llr=False)
+        if want is None:
+            want = (bits.copy(), ret.copy())
+        assert np.array_equal(bits, want[0]) and np.array_equal(ret, want[1])
+    assert len(set(ret.tolist())) > 1 and (ret >= 0).all()
+    assert dec.fallback_rounds == 0
+    dec.close()
+
+
+def test_host_link_measurement_entry():
+    """dvbs2_measure_host_copy (diagnostics of bench.py's host_link): argument checks and a plausible rate for every kind of host memory."""
+    import ctypes as C
+    h2d, d2h = C.c_double(), C.c_double()
+    assert capi.lib.dvbs2_measure_host_copy(0, 0, 1, 0, h2d, d2h) == capi.EINVAL
+    assert capi.lib.dvbs2_measure_host_copy(0, 1 << 20, 0, 0, h2d, d2h) == capi.EINVAL
+    assert capi.lib.dvbs2_measure_host_copy(0, 1 << 20, 1, 3, h2d, d2h) == capi.EINVAL
+    for kind, streams in ((0, 1), (0, 4), (1, 1), (2, 1)):
+        capi.check(capi.lib.dvbs2_measure_host_copy(0, 64 << 20, streams, kind, h2d, d2h))
+        assert 0.2 < h2d.value < 200.0 and 0.2 < d2h.value < 200.0, (kind, streams, h2d.value, d2h.value)
