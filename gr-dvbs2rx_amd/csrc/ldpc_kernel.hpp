@@ -6,6 +6,10 @@
 #include <cstdint>
 #include "demap_math.hpp"
 
+#ifndef DVBS2_STAG
+#define DVBS2_STAG 0 // staggered ordered steps of the block-scheme hazard layers (check_node_hazard); 0: workgroup barriers between the blocks (rounds 1-3); 2: staggered steps, barrier before the regular outputs
+#endif
+
 namespace dvbs2 {
 
 // Thread mapping: a workgroup of 12 wavefronts decodes a PAIR of FECFRAMEs in lockstep; wavefronts 0-5 own
@@ -85,24 +89,31 @@ constexpr int kGroupSpinMax = 1 << 12; // polls of ~2 us
 // only the two words themselves carry information, both live in one 8-byte slot (one cache line, one coherence point, and a
 // member's two updates are issued in order by one lane), and the reader fetches `lastbad` with an atomic read-modify-write after
 // it has seen the arrival count, so it observes every `lastbad` update of the members it counted.
-__device__ __forceinline__ int group_decide(int* gw /*{arrive, lastbad} of this frame's group*/, int members, int it, bool good, int spin_max = kGroupSpinMax)
+// Round 4: the two words are ONE 8-byte slot {arrive (low), lastbad (high)} and a passing member reads both with a single 64-bit atomic --
+// its own arrival is a returning 64-bit add, a poll a 64-bit load: one round trip to the L2 after the last member has arrived instead of
+// three (max, load, max; ~1 us each, 4-5 % of an update at the operating point), and arrive / lastbad are one consistent snapshot (the
+// reader can no longer see an arrival without the failure that member reported before it: both of a failing member's updates go to the
+// same 8 bytes, in order, at one atomic unit).
+__device__ __forceinline__ int group_decide(int* gw /*{arrive, lastbad} of this frame's group, 8-byte aligned*/, int members, int it, bool good, int spin_max = kGroupSpinMax)
 {
     if (!good) {
         __hip_atomic_fetch_max(gw + 1, it + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_fetch_add(gw, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return 0; // (nothing is waited for: both are fire-and-forget)
     }
-    __hip_atomic_fetch_add(gw, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned long long* gq = reinterpret_cast<unsigned long long*>(gw);
+    unsigned long long v = __hip_atomic_fetch_add(gq, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1ull; // (arrive < 2^32: no carry into lastbad)
     const int want = members * (it + 1);
     for (int spin = 0;; spin++) {
+        const int lastbad = (int)(v >> 32), arrive = (int)(uint32_t)v;
         // a member that already failed at this count settles it without waiting for the rest (the slow frames run ahead: a
         // failing pre-test skips the full test)
-        if (__hip_atomic_fetch_max(gw + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > it) return 0;
-        if (__hip_atomic_load(gw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) break;
+        if (lastbad > it) return 0;
+        if (arrive >= want) return 1; // everybody has reported for this count and nobody failed
         if (spin >= spin_max) return 2;
         __builtin_amdgcn_s_sleep(8);
+        v = __hip_atomic_load(gq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    return __hip_atomic_fetch_max(gw + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= it ? 1 : 0;
 }
 
 // Pinned instruction selection for the two spots where the compiler's canonical form costs more issue slots.
@@ -215,7 +226,11 @@ __device__ __forceinline__ void check_node(uint8_t* __restrict__ lds /*the whole
         // address = S0 + jj, minus 360 when jj >= thr; the two parity entries have rot = 0 (never wrap) except
         // the previous-parity entry of layer 0 (rot = 359)
         if (k >= DEG - 2 && !(LAYER0 && k == DEG - 1)) ad[k] = jjb + (int)ent[2 * k];
+#ifdef DVBS2_EXP_NOWRAP // TIMING EXPERIMENT ONLY (wrong results): what would one-add addresses and one-word entries be worth?
+        else ad[k] = jjb + (int)ent[2 * k];
+#else
         else ad[k] = wrap_addr(jj, jjb, jjb360, ent[2 * k], ent[2 * k + 1]);
+#endif
     }
 #pragma unroll
     for (int k = 0; k < DEG; k++) {
@@ -695,7 +710,9 @@ __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, con
                                                   int block, int block2 /*two-level walk: rows per outer block, 0 = off*/, const uint32_t* mw, uint32_t* nm, int own_in, int* carry,
                                                   uint32_t* tab /*lane_chain_words(block) of LDS scratch when the layer is a lane chain*/,
                                                   volatile int* hb_ctr, int& hb_epoch, const int hb_lane /*frame barrier state*/,
-                                                  unsigned long long* ph = nullptr /*timing builds: cycles per phase of this node (8 slots), else null*/)
+                                                  unsigned long long* ph = nullptr /*timing builds: cycles per phase of this node (8 slots), else null*/,
+                                                  volatile int* hz_ctr = nullptr /*staggered ordered steps (below): the frame's progress counter in LDS, null = barriers*/,
+                                                  int* hz_base = nullptr /*its value when this layer started (wave-uniform, carried from layer to layer)*/)
 {
     unsigned long long tph = ph ? __builtin_readcyclecounter() : 0ull;
 #define DVBS2_PH(i) do { if (ph) { const unsigned long long t_ = __builtin_readcyclecounter(); ph[i] += t_ - tph; tph = t_; } } while (0)
@@ -1050,9 +1067,38 @@ __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, con
             if ((sb >> 6) != ((sb + 2 * block2 - 1) >> 6)) lds_barrier();
         }
     }
+    // STAGGERED ORDERED STEPS (round 4; the block scheme only, hz_ctr != null). The rows of block k need what the rows of the blocks
+    // before it wrote -- nothing else couples the waves of a frame inside this layer. With a workgroup barrier after every block all
+    // six waves walk through all 360 / B steps together and the outputs of the regular entries (P3: 10 VALU instructions per edge, half
+    // the node) start when the LAST block is done. Here a wave only takes the steps of the blocks that hold its own rows: it waits until
+    // the frame's progress counter in LDS says that every part of every earlier block is done (a block that spans waves has one part
+    // per wave; LDS executes a wave's operations in order, so a part's writes are in place when its count lands), does its part, counts,
+    // and after its last block goes straight on to P3 -- the regular outputs of the early waves run under the ordered steps of the later
+    // ones, and the steps hand over wave to wave through one LDS word instead of through s_barrier. The counter only ever grows: *hz_base
+    // (the same in every wave of the frame) is its value at the start of the layer. Nothing here depends on the other frame of the
+    // workgroup. Order kept: layered_decoder.hh:53-55 (rows ascend; inside a block no two rows share a bit).
+    bool staggered = false;
+    if (hz_ctr != nullptr && !lane_chain && !two_level && !tlc) staggered = true; // wave-uniform
+    const int wlo = __builtin_amdgcn_readfirstlane(jj), whi = wlo + 63 < kM ? wlo + 63 : kM - 1; // rows of this wave (threads 360..383 mirror row 359)
+    int hz_total = 0;
     int rel = (work && !lane_chain && !two_level && !tlc) ? jj : 0x40000000;
     for (int start = (lane_chain || two_level || tlc) ? kM : 0; start < kM; start += block, rel -= block) {
-        if ((uint32_t)rel < (uint32_t)block) {
+        bool mine = true;
+        if (staggered) {
+            const int end = (start + block < kM ? start + block : kM) - 1;
+            mine = work && start <= whi && end >= wlo; // (uniform) this wave owns rows of the block
+            if (mine && hz_total > 0) {
+                // (a waiting wave must not take issue slots from the wave whose step everybody waits for: lowest priority while it polls)
+                const int target = *hz_base + hz_total;
+                if (*hz_ctr - target < 0) {
+                    __builtin_amdgcn_s_setprio(0);
+                    do __builtin_amdgcn_s_sleep(2); while (*hz_ctr - target < 0);
+                    __builtin_amdgcn_s_setprio(3);
+                }
+            }
+            hz_total += (end >> 6) - (start >> 6) + 1; // parts of this block = waves that own rows of it
+        }
+        if (mine && (uint32_t)rel < (uint32_t)block) {
             if constexpr (NC == 2) {
                 // two hazard entries: each one's magnitude sent back is min(partial min0, the other's magnitude) =
                 // med3(raw other, 0, min0) (min0 is already clamped to [0, 126])
@@ -1098,8 +1144,11 @@ __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, con
         }
         // the next block reads what this one wrote: a workgroup barrier, unless both blocks sit inside one and the
         // same wavefront (LDS operations of a wave execute in program order)
-        if ((start >> 6) != ((start + 2 * block - 1) >> 6)) lds_barrier();
+        if (staggered) { if (mine && hb_lane == 0) __hip_atomic_fetch_add(const_cast<int*>(hz_ctr), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+        else if ((start >> 6) != ((start + 2 * block - 1) >> 6)) lds_barrier();
     }
+    if (staggered) { *hz_base += hz_total; __builtin_amdgcn_s_setprio(1); if (DVBS2_STAG == 2) lds_barrier(); } // the outputs below give way to the waves that still step
+    else
     if (!lane_chain || !(LR || DEG <= 20)) lds_barrier(); // (uniform; the last phase of a two-barrier lane chain and the outputs below touch different bits)
     DVBS2_PH(6); // ordered steps of the block scheme + closing barrier / completion of the chain rows
     if constexpr (NC == 2) { mg[0] = clamp_mag(mg[0]); mg[1] = clamp_mag(mg[1]); } // raw in the loop (127 where no step ran: idle rows)
@@ -1190,7 +1239,7 @@ __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, con
 // state made the compiler spill the regular entries of EVERY four- and eight-entry layer around it, 9/10 normal's multi-pair
 // layers went from 12-17 k to 25-34 k cycles.)
 #define DVBS2_HAZ_CALL1(D, NCV, LRV, TLCV) { \
-        if (layer0) check_node_hazard<D, NCV, true, false, false, HZ2, LRV, TLCV>(lds_all, ent, jj, lb, work, block, block2, mw, nm, 0, nullptr, htab, hb_ctr, hb_epoch, hb_lane, hz_ph); else check_node_hazard<D, NCV, false, false, false, HZ2, LRV, TLCV>(lds_all, ent, jj, lb, work, block, block2, mw, nm, 0, nullptr, htab, hb_ctr, hb_epoch, hb_lane, hz_ph); }
+        if (layer0) check_node_hazard<D, NCV, true, false, false, HZ2, LRV, TLCV>(lds_all, ent, jj, lb, work, block, block2, mw, nm, 0, nullptr, htab, hb_ctr, hb_epoch, hb_lane, hz_ph, hz_ctr, &hz_base); else check_node_hazard<D, NCV, false, false, false, HZ2, LRV, TLCV>(lds_all, ent, jj, lb, work, block, block2, mw, nm, 0, nullptr, htab, hb_ctr, hb_epoch, hb_lane, hz_ph, hz_ctr, &hz_base); }
 #define DVBS2_HAZ_CALL(D, NCV) { if constexpr (D - 2 >= NCV) { \
         if constexpr (kTlc<DMAX, HZ2> && !SOFT && MINW == 1 && (NCV == 4 || NCV == 8)) { if (block2 > 0 && htab != nullptr) DVBS2_HAZ_CALL1(D, NCV, (DMAX >= kTlcLowRegMinDmax), true) else DVBS2_HAZ_CALL1(D, NCV, (kLowReg<DMAX, HZ2>), false) } \
         else DVBS2_HAZ_CALL1(D, NCV, (kLowReg<DMAX, HZ2>), false) } }
@@ -1383,7 +1432,7 @@ __global__ __launch_bounds__(SOLO ? kSoloThreads : kThreads, SOLO ? 4 : MINW) vo
         }
     }
     const bool untouched = finished; // never loaded: must not write state/iters/good back
-    if (tid == 0) { flags[0] = 0; flags[2] = 0; flags[3] = 0; flags[1] = finished ? 1 : 0; flags[4] = 0; flags[5] = 0; }
+    if (tid == 0) { flags[0] = 0; flags[2] = 0; flags[3] = 0; flags[1] = finished ? 1 : 0; flags[4] = 0; flags[5] = 0; flags[6] = 0; }
     // Frame barriers in software (bit 1 of the flag word; pair workgroups only): worth it for high-degree tables without hazard
     // layers -- few barriers, long layers: S2X B21 +12 %, S2X B10 +10 % -- and a loss where barriers are frequent (B4 -8 %: the
     // counter costs ~300 cycles per barrier against ~30 for s_barrier). Chosen per table by the host.
@@ -1391,6 +1440,8 @@ __global__ __launch_bounds__(SOLO ? kSoloThreads : kThreads, SOLO ? 4 : MINW) vo
     volatile int* hb_ctr = soft_bar ? flags + 4 : nullptr; // frame barrier counter (frame_barrier)
     int hb_epoch = 0;
     const int hb_lane = lane;
+    volatile int* const hz_ctr = (DVBS2_STAG && MINW == 1) ? flags + 6 : nullptr; // progress counter of the frame's ordered steps
+    int hz_base = 0;
     __syncthreads();
     TSTAMP(tB); tm_load = tB - tA;
 
