@@ -84,7 +84,6 @@ private:
     bool chain_plain_ = false;    // plain sweep kernel with the packed register chain for single-pair hazard layers
     bool soft_bar_ = false;       // per-frame software barriers (high-degree tables without hazard layers)
     int fallback_rounds_ = 0;
-    bool sticky_pretest_ = true;  // the syndrome pre-test re-tests the layer in which the last full test failed (ldpc_kernel.hpp; bit 3 of the flag word turns it off)
     bool pr_w1_ = false;          // parity-in-records kernel with one-dword records (check degree <= 4)
     bool hz2_ = false;            // the build with the heavy-hazard paths (ldpc_kernel.hpp, HZ2)
     bool solo_ = false;           // one frame per workgroup, complementary wave roles per CU (ldpc_kernel.hpp)

@@ -146,6 +146,11 @@ LdpcDecoderHip::LdpcDecoderHip(const LdpcTableDesc* table, int out_bits_message,
     if (const char* e = getenv("DVBS2_TWO_LEVEL")) two_level_on = atoi(e) != 0; // experiments / tests
     int lane_chain_max = 128; // measured: gains up to block 64, flat to 128, slightly negative at 180 (three steps per layer)
     if (const char* e = getenv("DVBS2_LANE_CHAIN_MAX")) lane_chain_max = std::min(180, atoi(e)); // experiments
+    // the 80-VGPR build (same rule as where dense_ is set below): no two-level lane chain (76 -> 349 spilled registers, round 3) and, since
+    // round 4, no single-pair lane chain either -- with its tables addressed as LDS (typed pointers, ldpc_kernel.hpp) the chain code made that
+    // build spill ten times as much (72 -> 725) and short 3/5 / 2/3 lost 30 %; its layers take the block scheme
+    bool dense_here = !pr_ && sched_.N < 64800 && dmax_ == 12 && 10 * sched_.conflict_layers >= 7 * sched_.q && 4 * half_lds_bytes(sched_.N) <= 160 * 1024;
+    if (const char* e = getenv("DVBS2_DENSE")) dense_here = !pr_ && dmax_ == 12 && atoi(e) != 0 && 4 * half_lds_bytes(sched_.N) <= 160 * 1024;
     for (int i = 0; i < sched_.q; i++) {
         const LdpcLayer& L = sched_.layers[i];
         uint32_t nc_code = 0;
@@ -160,7 +165,7 @@ LdpcDecoderHip::LdpcDecoderHip(const LdpcTableDesc* table, int out_bits_message,
         int order[64];
         for (int k = 0; k < L.cnt + 2; k++) order[k] = k;
         uint32_t chain = 0;
-        if (L.block <= lane_chain_max && nc_code == 2 && L.n_conflict == 2 && (L.cnt + 2 <= kLaneChainMaxDeg || dmax_ >= kLowRegMinDmax) &&
+        if (!dense_here && L.block <= lane_chain_max && nc_code == 2 && L.n_conflict == 2 && (L.cnt + 2 <= kLaneChainMaxDeg || dmax_ >= kLowRegMinDmax) &&
             (sched_.N / 360) * kSvWords >= lane_chain_words(L.block)) {
             const LdpcEntry& a = sched_.entries[L.entry_off], & b = sched_.entries[L.entry_off + 1];
             if (a.base == b.base) {
@@ -175,8 +180,6 @@ LdpcDecoderHip::LdpcDecoderHip(const LdpcTableDesc* table, int out_bits_message,
         // (the degree class 32 without the heavy-hazard paths walks the near pair as a lane chain inside the outer blocks -- the
         // two-level lane chain of check_node_hazard: the pair additionally has to be oriented like a single-pair chain, bit 12)
         // (not in the 80-VGPR build -- same rule as where dense_ is set below --: the chain's state does not fit there, 76 -> 349 spilled registers)
-        bool dense_here = !pr_ && sched_.N < 64800 && dmax_ == 12 && 10 * sched_.conflict_layers >= 7 * sched_.q && 4 * half_lds_bytes(sched_.N) <= 160 * 1024;
-        if (const char* e = getenv("DVBS2_DENSE")) dense_here = !pr_ && dmax_ == 12 && atoi(e) != 0 && 4 * half_lds_bytes(sched_.N) <= 160 * 1024;
         const bool tlc_build = tlc_class(dmax_) && !hz2_ && !pr_ && !dense_here;
         if (tlc_build && two_level_on && L.block < 360 && L.block <= lane_chain_max && (nc_code == 4 || nc_code == 8) &&
             (sched_.N / 360) * kSvWords >= lane_chain_words(L.block)) {
@@ -352,7 +355,6 @@ LdpcDecoderHip::LdpcDecoderHip(const LdpcTableDesc* table, int out_bits_message,
         const uint32_t hd[kRecHeaderWords] = { (uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32), (uint32_t)G_, (uint32_t)spin_max, 0, 0 };
         HIP_OK(hipMemcpy(d_recs_alloc_, hd, sizeof(hd), hipMemcpyHostToDevice));
     }
-    if (const char* e = getenv("DVBS2_STICKY_PRETEST")) sticky_pretest_ = atoi(e) != 0; // experiments: 0 = always pre-test layer `it mod q` (rounds 1-3)
     if (const char* e = getenv("DVBS2_RESOLVE_ROUNDS")) resolve_rounds_ = std::max(0, std::min(8, atoi(e))); // tests: 0 forces the host-side leftover path
     HIP_OK(hipMalloc(&d_flag_, 4 * kSlots));
     HIP_OK(hipHostMalloc(&h_flag_, 4 * kSlots));
@@ -399,7 +401,7 @@ void LdpcDecoderHip::launch_sweep(const int8_t* in, bool resume, int stop_on_goo
     la.iters = d_iters_ + fb; la.good = d_good_ + fb; la.target = resume ? d_target_ + fb : nullptr;
     const bool gs = gsync_on_ && !resume && stop_on_good; // group-synchronous stop: bit 2 of the flag word; its words start from zero
     if (gs) (void)hipMemsetAsync(d_gsync_ + 2 * (size_t)(frame_base / G_), 0, (size_t)((n_frames + G_ - 1) / G_) * 8, stream); // (frame_base is a multiple of the group size: enqueue())
-    la.n_frames = n_frames; la.N = sched_.N; la.K = sched_.K; la.q = sched_.q; la.cap = max_trials; la.stop_on_good = stop_on_good | (soft_bar_ ? 2 : 0) | (gs ? 4 : 0) | (sticky_pretest_ ? 0 : 8);
+    la.n_frames = n_frames; la.N = sched_.N; la.K = sched_.K; la.q = sched_.q; la.cap = max_trials; la.stop_on_good = stop_on_good | (soft_bar_ ? 2 : 0) | (gs ? 4 : 0);
     la.tdbg = d_tdbg_; la.lds_bytes = solo_ ? half_lds_bytes(sched_.N) : lds_bytes_; la.stream = stream; la.dense = dense_;
     la.v2 = pr_ ? pr_w1_ : v2_; la.solo = solo_; la.chain = chain_plain_; la.hz2 = hz2_; la.soft = soft_bar_; la.cu_slots = d_cu_slots_;
     la.dm = DemapFused{};

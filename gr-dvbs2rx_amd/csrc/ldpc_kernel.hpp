@@ -6,8 +6,11 @@
 #include <cstdint>
 #include "demap_math.hpp"
 
-#ifndef DVBS2_STAG
-#define DVBS2_STAG 0 // staggered ordered steps of the block-scheme hazard layers (check_node_hazard); 0: workgroup barriers between the blocks (rounds 1-3); 2: staggered steps, barrier before the regular outputs
+#ifndef DVBS2_FWALK_MAXDEG
+#define DVBS2_FWALK_MAXDEG 12 // measured (round 4, interleaved A/B): 8 -> B2 +8 %, B4 +0.5 %; 12 -> 3/5 normal +1 %, T2 2/3 +4 %, the one-frame class-12 tables +5 %; 16 -> B7 -1 %; 28 -> 8/9 normal -8 %, 5/6 -3 %
+#endif
+#ifndef DVBS2_FWALK
+#define DVBS2_FWALK 1 // float walk with four rows in flight in the plain lane chain of the degree class 8 (check_node_hazard)
 #endif
 
 namespace dvbs2 {
@@ -40,10 +43,25 @@ constexpr int kRecHeaderWords = 8; // [0,1] iters base, [2,3] group words base, 
 // per frame: N LLR bytes, then the sign-vector area (syndrome test; scratch of the ordered hazard phases during a sweep:
 // at least kChainScratchWords dwords, which is what short frames get instead of their small sign-vector area), then 8 flag words
 constexpr int kChainMaxBlock = 128;                                             // largest block walked as a register chain
-constexpr int kChainScratchWords = (kM + kChainMaxBlock) * 5;                   // (360 + block) x (16-byte record + 4-byte log)
+constexpr int kChainScratchWords = (kM + kChainMaxBlock) * 5 + 4;               // (360 + block) x (16-byte record + 4-byte log) + 16 bytes: the records are 16-byte aligned and the area starts at N, which is 8 mod 16 for short frames
 __host__ __device__ constexpr int sv_area_words(int N) { return (N / kM) * kSvWords > kChainScratchWords ? (N / kM) * kSvWords : kChainScratchWords; }
 __host__ __device__ constexpr size_t half_lds_bytes(int N) { return ((size_t)N + (size_t)sv_area_words(N) * 4 + 32 + 15) / 16 * 16; }
 
+// EVERY access to LDS goes through a pointer whose TYPE says address space 3. A generic pointer that the compiler cannot trace back
+// to the shared array (a function parameter, a pointer rebuilt from an integer for alignment, any `volatile` access) becomes a FLAT
+// instruction: 64-bit address arithmetic, the long way round through the vector-memory path, and -- because flat loads return out of
+// order with buffer loads -- an `s_waitcnt vmcnt(0) lgkmcnt(0)` at every use, which also waits for the message prefetch from HBM
+// and serialises "rows in flight". Round 4 found the lane-chain walks, their operand tables and logs, the flag words and the
+// software frame barrier all compiled that way (1 400 flat instructions in the degree class 8 alone): ~140 cycles per chain row.
+typedef __attribute__((address_space(3))) uint8_t lds_byte_t;
+typedef __attribute__((address_space(3))) uint32_t lds_u32_t;
+typedef __attribute__((address_space(3))) int lds_i32_t;
+typedef __attribute__((address_space(3))) float lds_f32_t;
+typedef float v4f32 __attribute__((ext_vector_type(4)));
+typedef uint32_t v2u32 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) v4f32 lds_v4f_t;
+typedef __attribute__((address_space(3))) v2u32 lds_v2u_t;
+template <class T> __device__ __forceinline__ T* lds_align16(lds_u32_t* p) { return reinterpret_cast<T*>(((uint32_t)(size_t)p + 15u) & ~15u); }
 __device__ __forceinline__ int wrap360(int t) { return t >= kM ? t - kM : t; }
 
 // Barrier of ONE FRAME's six waves. The two frames of a workgroup share a CU only to get three waves on every SIMD
@@ -52,12 +70,12 @@ __device__ __forceinline__ int wrap360(int t) { return t >= kM ? t - kM : t; }
 // or for an ordered hazard step; a barrier per frame lets the other frame's waves take the idle issue slots. gfx950 has
 // no named barriers, so it is a counter in the frame's LDS region: every wave adds one (LDS executes a wave's operations
 // in order, so its earlier writes are in place when the add lands) and polls until the count reaches the expected multiple of 6.
-__device__ __forceinline__ void frame_barrier(volatile int* ctr, int& epoch, int lane)
+__device__ __forceinline__ void frame_barrier(volatile lds_i32_t* ctr, int& epoch, int lane)
 {
     if (!ctr) { __syncthreads(); return; } // hardware barrier of the workgroup (the default)
     epoch += 6;
     asm volatile("" ::: "memory");
-    if (lane == 0) __hip_atomic_fetch_add(const_cast<int*>(ctr), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (lane == 0) __hip_atomic_fetch_add(const_cast<lds_i32_t*>(ctr), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     while (*ctr - epoch < 0) __builtin_amdgcn_s_sleep(1);
     asm volatile("" ::: "memory");
 }
@@ -65,7 +83,7 @@ __device__ __forceinline__ void frame_barrier(volatile int* ctr, int& epoch, int
 // The same where only LDS (the flag words) is handed over: without the wait for outstanding vector memory operations that
 // __syncthreads() implies -- the group report of group_decide() is two fire-and-forget atomics whose acknowledgement would
 // otherwise be waited for at the next barrier (short frames: 1.4 % of a sweep, measured).
-__device__ __forceinline__ void frame_barrier_lds(volatile int* ctr, int& epoch, int lane)
+__device__ __forceinline__ void frame_barrier_lds(volatile lds_i32_t* ctr, int& epoch, int lane)
 {
     if (ctr) { frame_barrier(ctr, epoch, lane); return; }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -135,7 +153,6 @@ __device__ __forceinline__ int mag_offset(int Lb, int mb)
 // LLR bytes are addressed with ABSOLUTE LDS addresses (the row index carries the frame's offset and the address of
 // the dynamic LDS array): going through the array symbol costs one `v_add_u32 v, <lds_all>, v` per access, because the
 // array's address is a link-time constant the compiler cannot fold into an address that inline asm produced.
-typedef __attribute__((address_space(3))) uint8_t lds_byte_t;
 __device__ __forceinline__ int lds_rd(int a) { return *reinterpret_cast<const lds_byte_t*>((size_t)(uint32_t)a); }
 __device__ __forceinline__ void lds_wr(int a, int v) { *reinterpret_cast<lds_byte_t*>((size_t)(uint32_t)a) = (uint8_t)v; }
 __device__ __forceinline__ int lds_address_of(const uint8_t* p) { return (int)(uint32_t)(size_t)(const lds_byte_t*)p; }
@@ -226,11 +243,7 @@ __device__ __forceinline__ void check_node(uint8_t* __restrict__ lds /*the whole
         // address = S0 + jj, minus 360 when jj >= thr; the two parity entries have rot = 0 (never wrap) except
         // the previous-parity entry of layer 0 (rot = 359)
         if (k >= DEG - 2 && !(LAYER0 && k == DEG - 1)) ad[k] = jjb + (int)ent[2 * k];
-#ifdef DVBS2_EXP_NOWRAP // TIMING EXPERIMENT ONLY (wrong results): what would one-add addresses and one-word entries be worth?
-        else ad[k] = jjb + (int)ent[2 * k];
-#else
         else ad[k] = wrap_addr(jj, jjb, jjb360, ent[2 * k], ent[2 * k + 1]);
-#endif
     }
 #pragma unroll
     for (int k = 0; k < DEG; k++) {
@@ -526,15 +539,15 @@ __device__ __forceinline__ float byte1_f32(uint32_t x) { return (float)((x >> 8)
 
 template <int DEG, int DMAX, bool P6>
 __device__ __forceinline__ void check_node_chain_v2(const uint32_t* ent /*S0w[DMAX], masks[NFIX + 2]*/, int jj, int jjb, bool work, int B,
-                                                    const uint32_t* mw, uint32_t* nm, uint32_t* tab /*LDS scratch*/,
-                                                    volatile int* hb_ctr, int& hb_epoch, const int hb_lane)
+                                                    const uint32_t* mw, uint32_t* nm, lds_u32_t* tab /*LDS scratch, 16-byte aligned*/,
+                                                    volatile lds_i32_t* hb_ctr, int& hb_epoch, const int hb_lane)
 {
     constexpr int NP = (DEG + 1) / 2;
     constexpr int NFIXH = (v2_nfix(DMAX) + 2) < DEG - 2 ? (v2_nfix(DMAX) + 2) : DEG - 2;
     constexpr bool ODD = (DEG & 1) != 0;
     constexpr bool KEEP_AD = DEG <= 16; // high degrees recompute the addresses in P4 instead of holding 30 registers across the phases
-    float4* rec = reinterpret_cast<float4*>(tab);                 // [360 + B] chain operands
-    float* logv = reinterpret_cast<float*>(tab) + 4 * (kM + kChainMaxBlock); // [360 + B] value that arrived at row r
+    lds_v4f_t* rec = reinterpret_cast<lds_v4f_t*>(tab);           // [360 + B] chain operands
+    lds_f32_t* logv = reinterpret_cast<lds_f32_t*>(tab) + 4 * (kM + kChainMaxBlock); // [360 + B] value that arrived at row r
     const bool head = work && jj < B, body = work && jj >= B;
     const bool middle = body && jj + B < kM; // rows whose new X value travels down the chain; the others (tails) end a chain
     int LbX = 0x80;
@@ -603,7 +616,7 @@ __device__ __forceinline__ void check_node_chain_v2(const uint32_t* ent /*S0w[DM
         const uint32_t fold = sxp ^ (sxp << 16);                                      // bit 31: parity of the signs of the regular entries (the inputs other than X and Y)
         const float sigma = as_f32(0x3f800000u | (fold & 0x80000000u));
         const int mY = (int)M0 >> 24;                                                 // Y's message (upper half of the pair, << 8)
-        float4 r;
+        v4f32 r;
         r.x = sigma;
         r.y = -sigma * (float)(128 + mY);
         r.z = (float)(Pm + 1);
@@ -613,11 +626,11 @@ __device__ __forceinline__ void check_node_chain_v2(const uint32_t* ent /*S0w[DM
     lds_barrier();
     if (head) {
         // rows past 359 read the padding of the table and log into the padding: no per-lane predicate in the loop
-        const float4* rp = rec + jj + B;
-        float* lp = logv + jj + B;
+        const lds_v4f_t* rp = rec + jj + B;
+        lds_f32_t* lp = logv + jj + B;
         const int nsteps = (kM - 1) / B; // rows jj + k B, k = 1 .. nsteps (the last one may lie in the padding)
         __builtin_amdgcn_s_setprio(3);
-        auto step = [&](const float4 rc) {
+        auto step = [&](const v4f32 rc) {
             *lp = c; lp += B;
             const float x = __builtin_fmaf(c, rc.x, rc.y);
             const float w = vmed3_f32(x, -rc.z, rc.z);
@@ -628,7 +641,7 @@ __device__ __forceinline__ void check_node_chain_v2(const uint32_t* ent /*S0w[DM
         // NEXT row in flight the walk ran at the LDS latency (~150 cycles per step, cycle stamps of round 3: 26.6 k cycles for the 179
         // steps of 3/4 normal's block-2 layer). Four rows are kept in flight; reads past the table (rows >= 360 + block) fetch
         // whatever lies there and are never used.
-        float4 q0 = rp[0], q1 = rp[B], q2 = rp[2 * B], q3 = rp[3 * B];
+        v4f32 q0 = rp[0], q1 = rp[B], q2 = rp[2 * B], q3 = rp[3 * B];
         rp += 4 * B;
         int k = 0;
         for (; k + 4 <= nsteps; k += 4) {
@@ -705,14 +718,13 @@ constexpr int kMaxHazard12Dmax = 28; // (the degree class 32 has the two-level w
 constexpr int kHazardWalk = 15; // header code: too many hazard entries, fall back to the single-wave chunk walk
 template <int DEG, int NC, bool LAYER0, bool PR = false, bool LAST = false, bool TWO = false /*two-level walk compiled in*/,
           bool LR = false /*low-register form (see check_node_lr): regular entries keep one packed word, their addresses are computed twice*/,
-          bool TLC = false /*two-level walk with the near pair as a LANE CHAIN (round 3), see below*/>
+          bool TLC = false /*two-level walk with the near pair as a LANE CHAIN (round 3), see below*/,
+          bool CHAINOK = true /*false: no lane chain in this build (the 80-VGPR build since round 4, see kLaneChainBuilt)*/>
 __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, const uint32_t* ent, int jj, int lb, bool work,
                                                   int block, int block2 /*two-level walk: rows per outer block, 0 = off*/, const uint32_t* mw, uint32_t* nm, int own_in, int* carry,
-                                                  uint32_t* tab /*lane_chain_words(block) of LDS scratch when the layer is a lane chain*/,
-                                                  volatile int* hb_ctr, int& hb_epoch, const int hb_lane /*frame barrier state*/,
-                                                  unsigned long long* ph = nullptr /*timing builds: cycles per phase of this node (8 slots), else null*/,
-                                                  volatile int* hz_ctr = nullptr /*staggered ordered steps (below): the frame's progress counter in LDS, null = barriers*/,
-                                                  int* hz_base = nullptr /*its value when this layer started (wave-uniform, carried from layer to layer)*/)
+                                                  lds_u32_t* tab /*lane_chain_words(block) of LDS scratch when the layer is a lane chain*/,
+                                                  volatile lds_i32_t* hb_ctr, int& hb_epoch, const int hb_lane /*frame barrier state*/,
+                                                  unsigned long long* ph = nullptr /*timing builds: cycles per phase of this node (8 slots), else null*/)
 {
     unsigned long long tph = ph ? __builtin_readcyclecounter() : 0ull;
 #define DVBS2_PH(i) do { if (ph) { const unsigned long long t_ = __builtin_readcyclecounter(); ph[i] += t_ - tph; tph = t_; } } while (0)
@@ -788,7 +800,7 @@ __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, con
     __builtin_amdgcn_s_setprio(3);
     bool lane_chain = false;
     // (the low-register form has room for it at every degree)
-    constexpr bool kLaneChainBuilt = NC == 2 && (LR || DEG <= kLaneChainMaxDeg) && !PR;
+    constexpr bool kLaneChainBuilt = NC == 2 && (LR || DEG <= kLaneChainMaxDeg) && !PR && CHAINOK;
     if constexpr (kLaneChainBuilt) lane_chain = tab != nullptr; // wave-uniform (header bit 12)
     if constexpr (kLaneChainBuilt) if (lane_chain) {
         // LANE CHAIN (one hazard pair, block <= 128, host-ordered so that entry 0's bit of row r is entry 1's bit of
@@ -809,9 +821,26 @@ __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, con
         // (The walk on exact small integers in float -- six instructions per step as in the packed chain node instead of ~20 -- was
         // measured here too in round 3: the 16-byte operand records and the float state cost every build of every degree class 4-6
         // VGPRs; B4 113.2 k -> 112.4 k, the 80-VGPR and one-frame builds -4 ... -8 %. It stays in the packed chain node.)
-        uint8_t* ulog = reinterpret_cast<uint8_t*>(tab + kM + block); // after the per-row records (360 rows + one block of padding)
+        lds_byte_t* ulog = reinterpret_cast<lds_byte_t*>(tab + kM + block); // after the per-row records (360 rows + one block of padding)
         int chained = 0x80;
+        // Round 4, degree class 8 (DVBS2_FWALK): the walk on exact small integers in float with the operands of FOUR rows in flight. The
+        // integer step is ~17 dependent VALU instructions and one record read ahead: a lone wave needs ~110 cycles per row either way
+        // (issue ~4 cycles per instruction, an LDS read 100-130), 1.4 k cycles for the 8-10 rows of table B4's chains. In float the step is
+        // six instructions (fma, two med3 with a negated operand, sub, add, clamp -- the packed chain node's step, check_node_chain_v2)
+        // and with four 16-byte records in flight the LDS latency is covered.
+        //   record of row r: { sigma, -sigma m1, P + 1, inp0 + 128 }  (sigma = +-1: partial sign; m1: entry 1's message, offset binary;
+        //   P: partial minimum); incoming entry-1 LLR c (offset binary):  x = sigma (c - m1), w = clamp(x, -(P+1), P+1),
+        //   out = w - sgn(w) = sgn(x) min(P, max(|x| - 1, 0)),  c' = clamp(inp0 + 128 + out, 0, 255)
+        constexpr bool kFloatWalk = (DVBS2_FWALK != 0) && DEG <= DVBS2_FWALK_MAXDEG && !LR && !PR;
+        lds_v4f_t* frec = lds_align16<lds_v4f_t>(tab);                                                   // [360 + block]
+        lds_f32_t* flog = reinterpret_cast<lds_f32_t*>(frec) + 4 * (kM + kChainMaxBlock);              // [360 + block]
         auto publish = [&]() {
+            if constexpr (kFloatWalk) {
+                const float sigma = as_f32(0x3f800000u | ((uint32_t)signs & 0x80000000u));
+                v4f32 r;
+                r.x = sigma; r.y = -sigma * (float)hmb[1]; r.z = (float)(min0 + 1); r.w = (float)(inp[0] + 128);
+                frec[jj] = r;
+            } else
             tab[jj] = ((uint32_t)inp[0] & 0x1ffu) | ((uint32_t)min0 << 9) | (((uint32_t)signs >> 31) << 16) | ((uint32_t)hmb[1] << 24);
         };
         const bool head = work && jj < block, body = work && jj >= block;
@@ -851,11 +880,37 @@ __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, con
         DVBS2_PH(1); // chain heads + publishing
         lds_barrier();
         DVBS2_PH(3); // barrier
+        if constexpr (kFloatWalk) { if (head) {
+            const lds_v4f_t* rp = frec + jj + block;
+            lds_f32_t* lp = flog + jj + block;
+            const int nsteps = (kM - 1) / block; // rows jj + k block, k = 1 .. nsteps (the last one may lie in the padding)
+            float c = (float)chained;
+            auto step = [&](const v4f32 rc) {
+                *lp = c; lp += block;
+                const float x = __builtin_fmaf(c, rc.x, rc.y);
+                const float w = vmed3_f32(x, -rc.z, rc.z);
+                const float f = w - vmed3_f32(w, -1.f, 1.f);
+                c = vmed3_f32(rc.w + f, 0.f, 255.f);
+            };
+            v4f32 q0 = rp[0], q1 = rp[block], q2 = rp[2 * block], q3 = rp[3 * block]; // (reads past the table fetch scratch that is never used)
+            rp += 4 * block;
+            int k = 0;
+            for (; k + 4 <= nsteps; k += 4) {
+                step(q0); q0 = rp[0];
+                step(q1); q1 = rp[block];
+                step(q2); q2 = rp[2 * block];
+                step(q3); q3 = rp[3 * block];
+                rp += 4 * block;
+            }
+            if (k < nsteps) { step(q0); k++; }
+            if (k < nsteps) { step(q1); k++; }
+            if (k < nsteps) { step(q2); k++; }
+        } } else
         if (head) {
             // rows past 359 read the padding of the table and log into the padding: no per-lane predicate in the loop; the record
             // of a tail row (last of its chain) is not written: what is computed from it is never used
-            const uint32_t* tp = tab + jj + block;
-            uint8_t* up = ulog + jj + block;
+            const lds_u32_t* tp = tab + jj + block;
+            lds_byte_t* up = ulog + jj + block;
             uint32_t t = *tp;
             for (int first = block; first < kM; first += block) {
                 const uint32_t tc = t;
@@ -881,7 +936,7 @@ __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, con
                 inp[0] = min(max(L0 - hmb[0], -128), 127);
                 mg[0] = mag_raw(L0, hmb[0]);
             }
-            const int L1 = ulog[jj];
+            const int L1 = kFloatWalk ? (int)flog[jj] : (int)ulog[jj];
             inp[1] = min(max(L1 - hmb[1], -128), 127);
             mg[1] = mag_raw(L1, hmb[1]);
             int o0, o1;
@@ -912,7 +967,7 @@ __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, con
     bool tlc = false;
     if constexpr (kTlcBuilt) tlc = block2 > 0 && tab != nullptr; // wave-uniform
     if constexpr (kTlcBuilt) if (tlc) {
-        uint8_t* ulog = reinterpret_cast<uint8_t*>(tab + kM + block);
+        lds_byte_t* ulog = reinterpret_cast<lds_byte_t*>(tab + kM + block);
         int chained = 0x80;
         const bool head = work && jj < block;
         int rnext = jj + block; // chain lanes: the next row to visit
@@ -1067,38 +1122,13 @@ __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, con
             if ((sb >> 6) != ((sb + 2 * block2 - 1) >> 6)) lds_barrier();
         }
     }
-    // STAGGERED ORDERED STEPS (round 4; the block scheme only, hz_ctr != null). The rows of block k need what the rows of the blocks
-    // before it wrote -- nothing else couples the waves of a frame inside this layer. With a workgroup barrier after every block all
-    // six waves walk through all 360 / B steps together and the outputs of the regular entries (P3: 10 VALU instructions per edge, half
-    // the node) start when the LAST block is done. Here a wave only takes the steps of the blocks that hold its own rows: it waits until
-    // the frame's progress counter in LDS says that every part of every earlier block is done (a block that spans waves has one part
-    // per wave; LDS executes a wave's operations in order, so a part's writes are in place when its count lands), does its part, counts,
-    // and after its last block goes straight on to P3 -- the regular outputs of the early waves run under the ordered steps of the later
-    // ones, and the steps hand over wave to wave through one LDS word instead of through s_barrier. The counter only ever grows: *hz_base
-    // (the same in every wave of the frame) is its value at the start of the layer. Nothing here depends on the other frame of the
-    // workgroup. Order kept: layered_decoder.hh:53-55 (rows ascend; inside a block no two rows share a bit).
-    bool staggered = false;
-    if (hz_ctr != nullptr && !lane_chain && !two_level && !tlc) staggered = true; // wave-uniform
-    const int wlo = __builtin_amdgcn_readfirstlane(jj), whi = wlo + 63 < kM ? wlo + 63 : kM - 1; // rows of this wave (threads 360..383 mirror row 359)
-    int hz_total = 0;
+    // (Round 4 measured the alternative to a workgroup barrier per block -- each wave takes only the steps of the blocks that hold its
+    // rows, waits for a progress counter in LDS and goes on to its regular outputs while later waves still step: bit-exact and 4-11 %
+    // SLOWER (9/10 normal -4 %, 3/5 -8 %, 8/9 -9 %, 2/3 -11 %): a hand-over through an LDS word costs ~300 cycles against ~30-50 for
+    // s_barrier, more than the overlapped outputs give back. notes/r04_experiments.md.)
     int rel = (work && !lane_chain && !two_level && !tlc) ? jj : 0x40000000;
     for (int start = (lane_chain || two_level || tlc) ? kM : 0; start < kM; start += block, rel -= block) {
-        bool mine = true;
-        if (staggered) {
-            const int end = (start + block < kM ? start + block : kM) - 1;
-            mine = work && start <= whi && end >= wlo; // (uniform) this wave owns rows of the block
-            if (mine && hz_total > 0) {
-                // (a waiting wave must not take issue slots from the wave whose step everybody waits for: lowest priority while it polls)
-                const int target = *hz_base + hz_total;
-                if (*hz_ctr - target < 0) {
-                    __builtin_amdgcn_s_setprio(0);
-                    do __builtin_amdgcn_s_sleep(2); while (*hz_ctr - target < 0);
-                    __builtin_amdgcn_s_setprio(3);
-                }
-            }
-            hz_total += (end >> 6) - (start >> 6) + 1; // parts of this block = waves that own rows of it
-        }
-        if (mine && (uint32_t)rel < (uint32_t)block) {
+        if ((uint32_t)rel < (uint32_t)block) {
             if constexpr (NC == 2) {
                 // two hazard entries: each one's magnitude sent back is min(partial min0, the other's magnitude) =
                 // med3(raw other, 0, min0) (min0 is already clamped to [0, 126])
@@ -1144,11 +1174,8 @@ __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, con
         }
         // the next block reads what this one wrote: a workgroup barrier, unless both blocks sit inside one and the
         // same wavefront (LDS operations of a wave execute in program order)
-        if (staggered) { if (mine && hb_lane == 0) __hip_atomic_fetch_add(const_cast<int*>(hz_ctr), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-        else if ((start >> 6) != ((start + 2 * block - 1) >> 6)) lds_barrier();
+        if ((start >> 6) != ((start + 2 * block - 1) >> 6)) lds_barrier();
     }
-    if (staggered) { *hz_base += hz_total; __builtin_amdgcn_s_setprio(1); if (DVBS2_STAG == 2) lds_barrier(); } // the outputs below give way to the waves that still step
-    else
     if (!lane_chain || !(LR || DEG <= 20)) lds_barrier(); // (uniform; the last phase of a two-barrier lane chain and the outputs below touch different bits)
     DVBS2_PH(6); // ordered steps of the block scheme + closing barrier / completion of the chain rows
     if constexpr (NC == 2) { mg[0] = clamp_mag(mg[0]); mg[1] = clamp_mag(mg[1]); } // raw in the loop (127 where no step ran: idle rows)
@@ -1239,7 +1266,7 @@ __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, con
 // state made the compiler spill the regular entries of EVERY four- and eight-entry layer around it, 9/10 normal's multi-pair
 // layers went from 12-17 k to 25-34 k cycles.)
 #define DVBS2_HAZ_CALL1(D, NCV, LRV, TLCV) { \
-        if (layer0) check_node_hazard<D, NCV, true, false, false, HZ2, LRV, TLCV>(lds_all, ent, jj, lb, work, block, block2, mw, nm, 0, nullptr, htab, hb_ctr, hb_epoch, hb_lane, hz_ph, hz_ctr, &hz_base); else check_node_hazard<D, NCV, false, false, false, HZ2, LRV, TLCV>(lds_all, ent, jj, lb, work, block, block2, mw, nm, 0, nullptr, htab, hb_ctr, hb_epoch, hb_lane, hz_ph, hz_ctr, &hz_base); }
+        if (layer0) check_node_hazard<D, NCV, true, false, false, HZ2, LRV, TLCV, (MINW == 1)>(lds_all, ent, jj, lb, work, block, block2, mw, nm, 0, nullptr, htab, hb_ctr, hb_epoch, hb_lane, hz_ph); else check_node_hazard<D, NCV, false, false, false, HZ2, LRV, TLCV, (MINW == 1)>(lds_all, ent, jj, lb, work, block, block2, mw, nm, 0, nullptr, htab, hb_ctr, hb_epoch, hb_lane, hz_ph); }
 #define DVBS2_HAZ_CALL(D, NCV) { if constexpr (D - 2 >= NCV) { \
         if constexpr (kTlc<DMAX, HZ2> && !SOFT && MINW == 1 && (NCV == 4 || NCV == 8)) { if (block2 > 0 && htab != nullptr) DVBS2_HAZ_CALL1(D, NCV, (DMAX >= kTlcLowRegMinDmax), true) else DVBS2_HAZ_CALL1(D, NCV, (kLowReg<DMAX, HZ2>), false) } \
         else DVBS2_HAZ_CALL1(D, NCV, (kLowReg<DMAX, HZ2>), false) } }
@@ -1267,13 +1294,13 @@ __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, con
 // Step 1 of the full syndrome test (see the kernel): the 360-bit sign vectors of all N / 360 groups, one thread per eight consecutive
 // LLR bytes; returns non-zero when one of this thread's bytes is a zero LLR. A function of its own, NOT inlined: inlined, its loop
 // perturbed the register allocation of the sweep and cost the never-converging batches -- where it never runs -- up to 4 % (S2X 154/180).
-__device__ __attribute__((noinline)) int syndrome_sign_vectors(const uint8_t* lds, uint32_t* sv, int N, int tid)
+__device__ __attribute__((noinline)) int syndrome_sign_vectors(const lds_byte_t* lds, lds_u32_t* sv, int N, int tid)
 {
-    uint8_t* svb = reinterpret_cast<uint8_t*>(sv);
+    lds_byte_t* svb = reinterpret_cast<lds_byte_t*>(sv);
     int zero = 0;
 #pragma unroll 2
     for (int blk = tid; blk < N / 8; blk += kHalf) {
-        const uint2 v = *reinterpret_cast<const uint2*>(lds + 8 * blk);
+        const v2u32 v = *reinterpret_cast<const lds_v2u_t*>(lds + 8 * blk);
         const uint32_t xa = v.x ^ 0x80808080u, xb = v.y ^ 0x80808080u; // two's complement: zero bytes = zero LLRs
         zero |= (int)((((xa - 0x01010101u) & ~xa) | ((xb - 0x01010101u) & ~xb)) & 0x80808080u);
         // sign bit of byte i -> bit i (offset binary: negative <=> bit 7 clear): bits 0, 8, 16, 24 gathered by a multiply
@@ -1304,7 +1331,7 @@ __global__ __launch_bounds__(SOLO ? kSoloThreads : kThreads, SOLO ? 4 : MINW) vo
     const uint32_t* __restrict__ recs, const uint32_t* __restrict__ wrecs /*per (layer, wave) sweep records*/,
     const int8_t* __restrict__ llr_in, uint8_t* __restrict__ state,
     uint32_t* __restrict__ msgs, int* __restrict__ iters, int* __restrict__ good, const int* __restrict__ target,
-    int n_frames, int N, int K, int q, int cap, int stop_on_good /*bit 0: stop at a good syndrome, bit 1: software frame barriers, bit 2: group-synchronous stop, bit 3: pre-test always on layer it mod q*/,
+    int n_frames, int N, int K, int q, int cap, int stop_on_good /*bit 0: stop at a good syndrome, bit 1: software frame barriers, bit 2: group-synchronous stop*/,
     unsigned long long* __restrict__ tdbg, int* __restrict__ cu_slots,
     const DemapFused dm /*mode != 0: a fresh decode takes XFECFRAME symbols and demaps while loading (llr_in is null then)*/)
 {
@@ -1327,7 +1354,7 @@ __global__ __launch_bounds__(SOLO ? kSoloThreads : kThreads, SOLO ? 4 : MINW) vo
     int solo_slot = -1, solo_pat = 0;
     if constexpr (SOLO) {
         // role election (the first words of LDS are scratch until the LLRs are loaded)
-        volatile int* e = reinterpret_cast<volatile int*>(lds_all); // [0..3] waves seen per SIMD, [4] workers so far, [5] pattern
+        volatile lds_i32_t* e = reinterpret_cast<volatile lds_i32_t*>((lds_byte_t*)lds_all); // [0..3] waves seen per SIMD, [4] workers so far, [5] pattern
         if (threadIdx.x < 8) e[threadIdx.x] = 0;
         __syncthreads();
         if (threadIdx.x == 0) {
@@ -1345,9 +1372,9 @@ __global__ __launch_bounds__(SOLO ? kSoloThreads : kThreads, SOLO ? 4 : MINW) vo
             uint32_t hw;
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
             const int simd = (int)((hw >> 4) & 3u);
-            const int rank = __hip_atomic_fetch_add(const_cast<int*>(e) + simd, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const int rank = __hip_atomic_fetch_add(const_cast<lds_i32_t*>(e) + simd, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             const bool two = ((simd >> 1) & 1) == solo_pat; // pattern 0 keeps both waves on SIMDs 0,1; pattern 1 on SIMDs 2,3
-            if (two || rank == 0) widx = __hip_atomic_fetch_add(const_cast<int*>(e) + 4, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (two || rank == 0) widx = __hip_atomic_fetch_add(const_cast<lds_i32_t*>(e) + 4, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         widx = __builtin_amdgcn_readfirstlane(widx);
         __syncthreads();
@@ -1363,11 +1390,11 @@ __global__ __launch_bounds__(SOLO ? kSoloThreads : kThreads, SOLO ? 4 : MINW) vo
     const int tid = SOLO ? solo_tid : (int)threadIdx.x - half * kHalf;
     const int lb_rel = half * (int)half_lds_bytes(N);
     const int lb = lb_rel + lds_address_of(lds_all); // absolute LDS address of this frame's region
-    uint8_t* lds = lds_all + lb_rel;
-    uint32_t* sv = reinterpret_cast<uint32_t*>(lds + N); // N % 8 == 0
-    volatile int* flags = reinterpret_cast<volatile int*>(sv + sv_area_words(N)); // [0] bad-or, [1] finished, [2] pre-test failed, [3] full test needed
-    volatile int* other_flags = reinterpret_cast<volatile int*>(
-        lds_all + (1 - half) * half_lds_bytes(N) + N + (size_t)sv_area_words(N) * 4);
+    lds_byte_t* lds = (lds_byte_t*)lds_all + lb_rel; // (typed pointers: see lds_byte_t)
+    lds_u32_t* sv = reinterpret_cast<lds_u32_t*>(lds + N); // N % 8 == 0
+    volatile lds_i32_t* flags = reinterpret_cast<volatile lds_i32_t*>(sv + sv_area_words(N)); // [0] bad-or, [1] finished, [2] pre-test failed, [3] full test needed
+    volatile lds_i32_t* other_flags = reinterpret_cast<volatile lds_i32_t*>(
+        (lds_byte_t*)lds_all + (1 - half) * (int)half_lds_bytes(N) + N + sv_area_words(N) * 4);
     const int f = SOLO ? (int)blockIdx.x : 2 * (int)blockIdx.x + half;
     const bool have_frame = f < n_frames;
     const int lane = tid & 63, wave = tid >> 6;
@@ -1410,7 +1437,7 @@ __global__ __launch_bounds__(SOLO ? kSoloThreads : kThreads, SOLO ? 4 : MINW) vo
                 uint2 v = src[c];
                 v.x ^= 0x80808080u; v.y ^= 0x80808080u;
                 const int n = 8 * c;
-                if (n < K) *reinterpret_cast<uint2*>(lds + n) = v; // K % 8 == 0
+                if (n < K) *reinterpret_cast<lds_v2u_t*>(lds + n) = (v2u32){ v.x, v.y }; // K % 8 == 0
                 else {
                     // pty[360*i + j] = parity[q*j + i] (layered_decoder.hh:150-152)
                     int r = n - K;
@@ -1427,21 +1454,19 @@ __global__ __launch_bounds__(SOLO ? kSoloThreads : kThreads, SOLO ? 4 : MINW) vo
             if (it >= tgt) finished = true; // nothing to do for this frame in this pass
             else {
                 const uint2* src = reinterpret_cast<const uint2*>(state + (size_t)f * N);
-                for (int c = tid; c < N / 8; c += kHalf) *reinterpret_cast<uint2*>(lds + 8 * c) = src[c];
+                for (int c = tid; c < N / 8; c += kHalf) { const uint2 v = src[c]; *reinterpret_cast<lds_v2u_t*>(lds + 8 * c) = (v2u32){ v.x, v.y }; }
             }
         }
     }
     const bool untouched = finished; // never loaded: must not write state/iters/good back
-    if (tid == 0) { flags[0] = 0; flags[2] = 0; flags[3] = 0; flags[1] = finished ? 1 : 0; flags[4] = 0; flags[5] = 0; flags[6] = 0; }
+    if (tid == 0) { flags[0] = 0; flags[2] = 0; flags[3] = 0; flags[1] = finished ? 1 : 0; flags[4] = 0; }
     // Frame barriers in software (bit 1 of the flag word; pair workgroups only): worth it for high-degree tables without hazard
     // layers -- few barriers, long layers: S2X B21 +12 %, S2X B10 +10 % -- and a loss where barriers are frequent (B4 -8 %: the
     // counter costs ~300 cycles per barrier against ~30 for s_barrier). Chosen per table by the host.
     constexpr bool soft_bar = SOFT; // (bit 1 of the flag word is what the host sets when it launches this build)
-    volatile int* hb_ctr = soft_bar ? flags + 4 : nullptr; // frame barrier counter (frame_barrier)
+    volatile lds_i32_t* hb_ctr = soft_bar ? flags + 4 : nullptr; // frame barrier counter (frame_barrier)
     int hb_epoch = 0;
     const int hb_lane = lane;
-    volatile int* const hz_ctr = (DVBS2_STAG && MINW == 1) ? flags + 6 : nullptr; // progress counter of the frame's ordered steps
-    int hz_base = 0;
     __syncthreads();
     TSTAMP(tB); tm_load = tB - tA;
 
@@ -1498,13 +1523,11 @@ __global__ __launch_bounds__(SOLO ? kSoloThreads : kThreads, SOLO ? 4 : MINW) vo
         const bool need_synd = !finished && ((stop_on_good & 1) || it >= tgt);
         // Pre-test (the reference's bad() also returns at the first failing check): the 360 checks of ONE layer,
         // tested edge by edge. A failure here is final; only a frame that passes pays for the full test below.
-        // WHICH layer is pre-tested is free (any failing check makes the batch bad; a pass is followed by the full test): round 4 keeps
-        // the layer in which the last full test found an unsatisfied check (flags[5] = layer + 1) -- near convergence the few wrong bits
-        // keep the same checks unsatisfied for several updates, so a frame pays for a full test only when that layer has become clean
-        // (operating point: most updates of a converging frame used to run the full test), and falls back to layer `it mod q`.
+        // (Round 4 measured a "sticky" choice of the pre-tested layer -- the layer in which the last full test found an unsatisfied check
+        // instead of `it mod q`, so that a nearly converged frame skips full tests: exact, and no measurable change at the operating point
+        // of bench.py (282.8 k vs 282.9 k frames/s): the full test is ~3 % of an update in which it runs. Not kept.)
         if (need_synd && active) {
-            const int hint = (stop_on_good & 8) ? 0 : flags[5];
-            const int i0 = hint ? hint - 1 : it % q;
+            const int i0 = it % q;
             const uint32_t* rec = recs + (size_t)i0 * RS;
             const int deg = (int)(rec[0] & 0xffu) + 2;
             uint32_t x = 0, z = 0;
@@ -1538,7 +1561,7 @@ __global__ __launch_bounds__(SOLO ? kSoloThreads : kThreads, SOLO ? 4 : MINW) vo
         TSTAMP(tC); tm_s1 += tC - tS0;
         lds_barrier();
         if (need_full && tid < NG) { // wrap extension: bits 360+u = bit u
-            uint32_t* p = sv + tid * kSvWords;
+            lds_u32_t* p = sv + tid * kSvWords;
             const uint32_t w0 = p[0], w1 = p[1];
             p[11] = (p[11] & 0xffu) | (w0 << 8);
             p[12] = (w0 >> 24) | (w1 << 8);
@@ -1563,14 +1586,14 @@ __global__ __launch_bounds__(SOLO ? kSoloThreads : kThreads, SOLO ? 4 : MINW) vo
                         const int rot = kM - (int)e1[k];   // S0 = 360*g + rot, thr = 360 - rot
                         const int g360 = (int)e0[k] - rot;
                         const int t0 = wrap360(32 * w + rot);
-                        const uint32_t* p = sv + (g360 / kM) * kSvWords + (t0 >> 5);
+                        const lds_u32_t* p = sv + (g360 / kM) * kSvWords + (t0 >> 5);
                         uint32_t x = __funnelshift_r(p[0], p[1], t0 & 31);
                         if (i == 0 && k == deg - 1 && w == 0) x &= ~1u; // check (0,0): no previous parity
                         acc ^= x;
                     }
                 }
                 if (w == 11) acc &= 0xffu;
-                if (acc != 0) { bad = 1; flags[5] = i + 1; } // (any failing layer will do as the next pre-test: a benign race)
+                bad |= acc != 0;
             }
             if (__ballot(bad) != 0 && lane == 0) flags[0] = 1;
         }
@@ -1639,7 +1662,7 @@ __global__ __launch_bounds__(SOLO ? kSoloThreads : kThreads, SOLO ? 4 : MINW) vo
             prefetch(0u);
             const int deg = (int)(hdr & 0xffu) + 2;
             const int nc = (int)((hdr >> 8) & 0xfu);
-            uint32_t* htab = ((hdr >> 12) & 1u) ? sv : nullptr; // lane-chain scratch: the sign-vector area is idle during a sweep
+            lds_u32_t* htab = ((hdr >> 12) & 1u) ? sv : nullptr; // lane-chain scratch: the sign-vector area is idle during a sweep
             const int block = (int)(hdr >> 16);
             int block2 = 0; // hazard layers: rows per outer block of the two-level walk (0: off)
             if constexpr (HZ2 || (kTlc<DMAX, HZ2> && !SOFT && MINW == 1)) { if (block < kM) block2 = (int)wr[(size_t)i * RSW + 2]; }
@@ -1687,7 +1710,7 @@ __global__ __launch_bounds__(SOLO ? kSoloThreads : kThreads, SOLO ? 4 : MINW) vo
                     if (work && i + 1 < q && !zero_msgs) msg_load(pre, mso + kLayerBytes, row4, npacked, ndeg);
                     if constexpr ((V2 || CHAIN) && DMAX <= 16) { // (the chain node's register state costs the high-degree builds more than it saves: not built there)
                         if (hv2) {
-                            uint32_t* htab16 = reinterpret_cast<uint32_t*>((reinterpret_cast<size_t>(sv) + 15) & ~(size_t)15); // 16-byte records
+                            lds_u32_t* htab16 = lds_align16<lds_u32_t>(sv); // 16-byte records
                             DVBS2_CHAIN_SWITCH
                         } else DVBS2_HAZ_SWITCH
                     } else DVBS2_HAZ_SWITCH
@@ -1729,7 +1752,7 @@ __global__ __launch_bounds__(SOLO ? kSoloThreads : kThreads, SOLO ? 4 : MINW) vo
     if (have_frame && !untouched) {
         if (tid == 0) { iters[f] = it; good[f] = is_good ? 1 : 0; }
         uint2* dst = reinterpret_cast<uint2*>(state + (size_t)f * N);
-        for (int c = tid; c < N / 8; c += kHalf) dst[c] = *reinterpret_cast<const uint2*>(lds + 8 * c);
+        for (int c = tid; c < N / 8; c += kHalf) { const v2u32 v = *reinterpret_cast<const lds_v2u_t*>(lds + 8 * c); dst[c] = make_uint2(v.x, v.y); }
     }
     if constexpr (SOLO) { // give the CU's pattern slot back
         if (tid == 0) __hip_atomic_fetch_add(cu_slots + solo_slot, solo_pat ? -0x10000 : -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -118,7 +118,7 @@ template <bool W1>
 __global__ __launch_bounds__(kThreads, 6) void ldpc_layered_pr_kernel(
     const uint32_t* __restrict__ recs, const int8_t* __restrict__ llr_in, uint8_t* __restrict__ state,
     uint32_t* __restrict__ msgs, int* __restrict__ iters, int* __restrict__ good, const int* __restrict__ target,
-    int n_frames, int N, int K, int q, int cap, int stop_on_good /*bit 0: stop at a good syndrome, bit 2: group-synchronous stop (ldpc_kernel.hpp, group_decide), bit 3: pre-test always on layer it mod q*/)
+    int n_frames, int N, int K, int q, int cap, int stop_on_good /*bit 0: stop at a good syndrome, bit 2: group-synchronous stop (ldpc_kernel.hpp, group_decide)*/)
 {
     if (!llr_in) { // resume launch: a workgroup whose frames are both at their target leaves before touching LDS
         const int fa = 2 * (int)blockIdx.x, fb = fa + 1;
@@ -133,11 +133,11 @@ __global__ __launch_bounds__(kThreads, 6) void ldpc_layered_pr_kernel(
     const int tid = threadIdx.x - half * kHalf;
     const int lb_rel = half * (int)pr_half_bytes(K);
     const int lb = lb_rel + lds_address_of(lds_all); // absolute LDS address of this frame's region
-    uint8_t* lds = lds_all + lb_rel;
-    uint32_t* sv = reinterpret_cast<uint32_t*>(lds_all + 2 * pr_half_bytes(K));
-    volatile int* flags_all = reinterpret_cast<volatile int*>(sv + (N / kM) * kSvWords);
-    volatile int* flags = flags_all + 8 * half;        // [0] bad-or, [1] finished, [2] pre-test failed, [3] full test needed
-    volatile int* other_flags = flags_all + 8 * (1 - half);
+    lds_byte_t* lds = (lds_byte_t*)lds_all + lb_rel; // (address-space-3 typed pointers: ldpc_kernel.hpp, lds_byte_t)
+    lds_u32_t* sv = reinterpret_cast<lds_u32_t*>((lds_byte_t*)lds_all + 2 * (int)pr_half_bytes(K));
+    volatile lds_i32_t* flags_all = reinterpret_cast<volatile lds_i32_t*>(sv + (N / kM) * kSvWords);
+    volatile lds_i32_t* flags = flags_all + 8 * half;        // [0] bad-or, [1] finished, [2] pre-test failed, [3] full test needed
+    volatile lds_i32_t* other_flags = flags_all + 8 * (1 - half);
     const int f = 2 * blockIdx.x + half;
     const bool have_frame = f < n_frames;
     const int lane = tid & 63, wave = tid >> 6;
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(kThreads, 6) void ldpc_layered_pr_kernel(
             for (int c = tid; c < K / 8; c += kHalf) {
                 uint2 v = src8[c];
                 v.x ^= 0x80808080u; v.y ^= 0x80808080u;
-                *reinterpret_cast<uint2*>(lds + 8 * c) = v;
+                *reinterpret_cast<lds_v2u_t*>(lds + 8 * c) = (v2u32){ v.x, v.y };
             }
             if (active) {
                 // parity[q*j + i] = P[i][j] (layered_decoder.hh:150-152): row q-1 to LDS, row i < q-1 to byte 7 of
@@ -184,13 +184,13 @@ __global__ __launch_bounds__(kThreads, 6) void ldpc_layered_pr_kernel(
                 // resume: information LLRs and parity row q-1 come back from the state buffer; the other parity rows
                 // are still in the message records
                 const uint2* src8 = reinterpret_cast<const uint2*>(state + (size_t)f * N);
-                for (int c = tid; c < K / 8; c += kHalf) *reinterpret_cast<uint2*>(lds + 8 * c) = src8[c];
+                for (int c = tid; c < K / 8; c += kHalf) { const uint2 v = src8[c]; *reinterpret_cast<lds_v2u_t*>(lds + 8 * c) = (v2u32){ v.x, v.y }; }
                 if (active) lds[K + tid] = state[(size_t)f * N + K + kM * (q - 1) + tid];
             }
         }
     }
     const bool untouched = finished;
-    if (tid == 0) { flags[0] = 0; flags[2] = 0; flags[3] = 0; flags[1] = finished ? 1 : 0; flags[5] = 0; }
+    if (tid == 0) { flags[0] = 0; flags[2] = 0; flags[3] = 0; flags[1] = finished ? 1 : 0; }
     __syncthreads();
 
     bool is_good = false;
@@ -198,8 +198,7 @@ __global__ __launch_bounds__(kThreads, 6) void ldpc_layered_pr_kernel(
         // ---- syndrome test: pre-test on one layer, full test only for frames that pass it (see ldpc_kernel.hpp) ----
         const bool need_synd = !finished && ((stop_on_good & 1) || it >= tgt);
         if (need_synd && active) {
-            const int hint = (stop_on_good & 8) ? 0 : flags[5]; // layer + 1 in which the last full test found an unsatisfied check (ldpc_kernel.hpp)
-            const int i0 = hint ? hint - 1 : it % q;
+            const int i0 = it % q;
             const uint32_t* rec = recs + (size_t)i0 * RS;
             const int deg = (int)(rec[0] & 0xffu) + 2;
             uint32_t x = 0, z = 0;
@@ -237,13 +236,13 @@ __global__ __launch_bounds__(kThreads, 6) void ldpc_layered_pr_kernel(
                         }
                         const unsigned long long neg = __ballot(v < 0x80u);
                         zero_any |= __ballot(v == 0x80u);
-                        if (lane == 0) *reinterpret_cast<uint2*>(&sv[g * kSvWords + 2 * wave]) = make_uint2((uint32_t)neg, (uint32_t)(neg >> 32));
+                        if (lane == 0) *reinterpret_cast<lds_v2u_t*>(&sv[g * kSvWords + 2 * wave]) = (v2u32){ (uint32_t)neg, (uint32_t)(neg >> 32) };
                     }
                     if (zero_any != 0 && lane == 0) flags[0] = 1;
                 }
                 __syncthreads();
                 if (mine && tid < NG) {
-                    uint32_t* p = sv + tid * kSvWords;
+                    lds_u32_t* p = sv + tid * kSvWords;
                     const uint32_t w0 = p[0], w1 = p[1];
                     p[11] = (p[11] & 0xffu) | (w0 << 8);
                     p[12] = (w0 >> 24) | (w1 << 8);
@@ -262,13 +261,13 @@ __global__ __launch_bounds__(kThreads, 6) void ldpc_layered_pr_kernel(
                             else if (k == deg - 1) { g = NGD + (i ? i - 1 : q - 1); rot = i ? 0 : 359; } // previous parity
                             else { rot = kM - (int)rec[5 + 2 * k]; g = ((int)rec[4 + 2 * k] - rot) / kM; }
                             const int t0 = wrap360(32 * w + rot);
-                            const uint32_t* p = sv + g * kSvWords + (t0 >> 5);
+                            const lds_u32_t* p = sv + g * kSvWords + (t0 >> 5);
                             uint32_t x = __funnelshift_r(p[0], p[1], t0 & 31);
                             if (i == 0 && k == deg - 1 && w == 0) x &= ~1u;
                             acc ^= x;
                         }
                         if (w == 11) acc &= 0xffu;
-                        if (acc != 0) { bad = 1; flags[5] = i + 1; }
+                        bad |= acc != 0;
                     }
                     if (__ballot(bad) != 0 && lane == 0) flags[0] = 1;
                 }
@@ -371,7 +370,7 @@ __global__ __launch_bounds__(kThreads, 6) void ldpc_layered_pr_kernel(
     if (have_frame && !untouched) {
         if (tid == 0) { iters[f] = it; good[f] = is_good ? 1 : 0; }
         uint8_t* dst = state + (size_t)f * N;
-        for (int c = tid; c < K / 8; c += kHalf) reinterpret_cast<uint2*>(dst)[c] = *reinterpret_cast<const uint2*>(lds + 8 * c);
+        for (int c = tid; c < K / 8; c += kHalf) { const v2u32 v = *reinterpret_cast<const lds_v2u_t*>(lds + 8 * c); reinterpret_cast<uint2*>(dst)[c] = make_uint2(v.x, v.y); }
         if (active) {
             for (int i = 0; i < q - 1; i++) dst[K + kM * i + tid] = (uint8_t)(msg_base[((i + 1) * RW + PW) * kMsgStride + tid] >> 24);
             dst[K + kM * (q - 1) + tid] = lds[K + tid];

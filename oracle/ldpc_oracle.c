@@ -17,8 +17,9 @@
  *     table walk    lib/ldpc_decoder/ldpc.hh:44-87 (bit m of a group with row x -> checks (x+m*q) mod R)
  *
  * Parity pin: checked byte-for-byte (LLRs and return value) against the genuine reference decoders
- * built by oracle/Makefile into oracle/_ref/ (tests/test_oracle_vs_ref.py, build container only) and
- * against the golden digests in tests/golden/ldpc_golden.json generated from those reference builds.
+ * built by oracle/Makefile into oracle/_ref/ (tests/test_oracle_kat.py::test_ldpc_oracle_vs_reference_live, wherever the prebuilt
+ * oracle/_ref/ is present) and against the golden digests in tests/golden/ldpc_golden.json generated from those reference builds
+ * (tools/gen_ldpc_golden.py; test_ldpc_oracle_matches_reference_digests).
  */
 #include <stdint.h>
 #include <stdlib.h>

@@ -534,21 +534,6 @@ def test_group_stop_fallback_when_members_give_up(monkeypatch, table, amp, sigma
         assert len(set(r32.tolist())) > 1
 
 
-@pytest.mark.parametrize("table,amp,sigma", [("S2_TABLE_B4", 6, 5.2), ("S2_TABLE_C1", 5, 6.5), ("S2_TABLE_B7", 8, 3.6)])
-@pytest.mark.parametrize("sticky", ["1", "0"])
-def test_syndrome_pretest_layer_choice(monkeypatch, table, amp, sigma, sticky):
-    """Round 4: the syndrome pre-test re-tests the layer in which the last full test found an unsatisfied check instead of layer
-    `it mod q` (csrc/ldpc_kernel.hpp). Which layer is pre-tested must not show in any output: frames that converge at different
-    counts, one that never does and one clean codeword, against the reference, with the choice on and off."""
-    monkeypatch.setenv("DVBS2_STICKY_PRETEST", sticky)
-    llr, _ = T.llr_codeword_awgn(table, 96, 4321, amp=amp, sigma=sigma)
-    llr[5] = T.llr_noise(1, llr.shape[1], 8)[0]
-    llr[40] = T.llr_codeword_awgn(table, 1, 7, amp=20, sigma=0.0)[0][0]
-    r = compare(table, llr, 32, 50)
-    assert len(set(r.tolist())) > 1
-    compare(table, llr[:48], 16, 50)
-
-
 def test_group_stop_needs_no_host_round_at_the_default_threshold():
     """a member that gives up waiting for its group is repaired by host-driven rounds (finish()); at the default
     give-up threshold that must not happen -- the library counts those rounds (dvbs2_ldpc_fallback_rounds) and a converging batch of
