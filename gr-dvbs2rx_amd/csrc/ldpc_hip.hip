@@ -149,8 +149,17 @@ LdpcDecoderHip::LdpcDecoderHip(const LdpcTableDesc* table, int out_bits_message,
     // the 80-VGPR build (same rule as where dense_ is set below): no two-level lane chain (76 -> 349 spilled registers, round 3) and, since
     // round 4, no single-pair lane chain either -- with its tables addressed as LDS (typed pointers, ldpc_kernel.hpp) the chain code made that
     // build spill ten times as much (72 -> 725) and short 3/5 / 2/3 lost 30 %; its layers take the block scheme
-    bool dense_here = !pr_ && sched_.N < 64800 && dmax_ == 12 && 10 * sched_.conflict_layers >= 7 * sched_.q && 4 * half_lds_bytes(sched_.N) <= 160 * 1024;
-    if (const char* e = getenv("DVBS2_DENSE")) dense_here = !pr_ && dmax_ == 12 && atoi(e) != 0 && 4 * half_lds_bytes(sched_.N) <= 160 * 1024;
+    // (the build -- 80 VGPRs, one frame per workgroup, software frame barriers -- is decided HERE, once, before the records are laid out for it)
+    dense_ = !pr_ && sched_.N < 64800 && dmax_ == 12 && 10 * sched_.conflict_layers >= 7 * sched_.q && 4 * half_lds_bytes(sched_.N) <= 160 * 1024;
+    if (const char* e = getenv("DVBS2_DENSE")) dense_ = !pr_ && dmax_ == 12 && atoi(e) != 0 && 4 * half_lds_bytes(sched_.N) <= 160 * 1024;
+    const bool dense_here = dense_;
+    const bool timing_on = getenv("DVBS2_TIMING") != nullptr;
+    solo_ = !pr_ && !dense_ && !hz2_ && dmax_ <= 16 && pol_solo;
+    if (const char* e = getenv("DVBS2_SOLO")) solo_ = !pr_ && !dense_ && !hz2_ && dmax_ <= 16 && atoi(e) != 0;
+    if (timing_on) solo_ = false;
+    soft_bar_ = !pr_ && !dense_ && !solo_ && dmax_ >= 20 && sched_.conflict_layers == 0; // frame barriers in software (ldpc_kernel.hpp)
+    if (const char* e = getenv("DVBS2_SOFT_BARRIER")) soft_bar_ = !pr_ && !dense_ && !solo_ && dmax_ >= 20 && atoi(e) != 0; // (built for the degree classes >= 20)
+    if (hz2_ || timing_on) soft_bar_ = false;
     for (int i = 0; i < sched_.q; i++) {
         const LdpcLayer& L = sched_.layers[i];
         uint32_t nc_code = 0;
@@ -180,7 +189,7 @@ LdpcDecoderHip::LdpcDecoderHip(const LdpcTableDesc* table, int out_bits_message,
         // (the degree class 32 without the heavy-hazard paths walks the near pair as a lane chain inside the outer blocks -- the
         // two-level lane chain of check_node_hazard: the pair additionally has to be oriented like a single-pair chain, bit 12)
         // (not in the 80-VGPR build -- same rule as where dense_ is set below --: the chain's state does not fit there, 76 -> 349 spilled registers)
-        const bool tlc_build = tlc_class(dmax_) && !hz2_ && !pr_ && !dense_here;
+        const bool tlc_build = tlc_class(dmax_) && !hz2_ && !pr_ && !dense_here && !soft_bar_; // (kTlc<DMAX, HZ2> && !SOFT && MINW == 1 in the kernel)
         if (tlc_build && two_level_on && L.block < 360 && L.block <= lane_chain_max && (nc_code == 4 || nc_code == 8) &&
             (sched_.N / 360) * kSvWords >= lane_chain_words(L.block)) {
             int best_a = -1, best_b = -1, d1 = 360, d2 = 360;
@@ -245,9 +254,7 @@ LdpcDecoderHip::LdpcDecoderHip(const LdpcTableDesc* table, int out_bits_message,
     // Short frames whose layers are mostly hazard layers (latency-bound ordered steps) and whose degree rules out the
     // parity-in-records kernel: the 80-VGPR build puts a second workgroup on the CU (measured: short 3/5 and 2/3 +34 %;
     // it costs 6-18 % where regular layers dominate, hence the 70 % threshold; degree classes above 12 do not fit 80 VGPRs). DVBS2_DENSE=0 / 1 overrides.
-    dense_ = !pr_ && sched_.N < 64800 && dmax_ == 12 && 10 * sched_.conflict_layers >= 7 * sched_.q &&
-             4 * half_lds_bytes(sched_.N) <= 160 * 1024;
-    if (const char* e = getenv("DVBS2_DENSE")) dense_ = !pr_ && dmax_ == 12 && atoi(e) != 0 && 4 * half_lds_bytes(sched_.N) <= 160 * 1024;
+    // (dense_ was decided before the records were laid out)
     // Sweep records per (layer, wave) for the classic kernel (check_node_v2 in ldpc_kernel.hpp). A regular layer i > 0 gets,
     // for each of the six waves of a frame, its data entries reordered "mixed first" (mixed = the wrap point 360 - rot lies
     // inside the wave's rows), window offsets pre-adjusted for the wave, and the lane masks of the mixed entries; a wave
@@ -361,12 +368,6 @@ LdpcDecoderHip::LdpcDecoderHip(const LdpcTableDesc* table, int out_bits_message,
     HIP_OK(hipEventCreate(&ev0_));
     HIP_OK(hipEventCreate(&ev1_));
     if (getenv("DVBS2_TIMING")) { HIP_OK(hipMalloc(&d_tdbg_, ((size_t)max_frames_ * 48 + 512) * 8)); HIP_OK(hipMemset(d_tdbg_, 0, ((size_t)max_frames_ * 48 + 512) * 8)); }
-    solo_ = !pr_ && !dense_ && !hz2_ && dmax_ <= 16 && pol_solo;
-    if (const char* e = getenv("DVBS2_SOLO")) solo_ = !pr_ && !dense_ && !hz2_ && dmax_ <= 16 && atoi(e) != 0;
-    if (d_tdbg_) solo_ = false;
-    soft_bar_ = !pr_ && !dense_ && !solo_ && dmax_ >= 20 && sched_.conflict_layers == 0; // frame barriers in software (ldpc_kernel.hpp)
-    if (const char* e = getenv("DVBS2_SOFT_BARRIER")) soft_bar_ = !pr_ && !dense_ && !solo_ && dmax_ >= 20 && atoi(e) != 0; // (built for the degree classes >= 20)
-    if (hz2_ || d_tdbg_) soft_bar_ = false;
     if (solo_) { HIP_OK(hipMalloc(&d_cu_slots_, kCuSlots * 4)); HIP_OK(hipMemset(d_cu_slots_, 0, kCuSlots * 4)); }
     kname_ = pr_ ? std::string(pr_w1_ ? "ldpc_layered_pr_kernel<w1>" : "ldpc_layered_pr_kernel") : "ldpc_layered_kernel<" + std::to_string(dmax_) + (dense_ ? ", dense>" : std::string(v2_ ? ", packed" : chain_plain_ ? ", chain" : "") + (solo_ ? ", solo>" : hz2_ ? ", hz2>" : soft_bar_ ? ", soft>" : ">"));
     lds_bytes_ = pr_ ? pr_lds_bytes(sched_.N, sched_.K) : 2 * half_lds_bytes(sched_.N);

@@ -72,6 +72,8 @@ __device__ __forceinline__ int wrap360(int t) { return t >= kM ? t - kM : t; }
 // in order, so its earlier writes are in place when the add lands) and polls until the count reaches the expected multiple of 6.
 __device__ __forceinline__ void frame_barrier(volatile lds_i32_t* ctr, int& epoch, int lane)
 {
+    // (Round 4, with no FLAT access left in the kernel: the barrier without the wait for outstanding vector memory operations that
+    // __syncthreads() implies -- s_waitcnt lgkmcnt(0) + s_barrier -- measured again: +-0.3 % on every BASELINE table. Not used.)
     if (!ctr) { __syncthreads(); return; } // hardware barrier of the workgroup (the default)
     epoch += 6;
     asm volatile("" ::: "memory");
