@@ -94,6 +94,47 @@ DEF(xor3, "v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96")
 DEF(lshl_add, "v_lshl_add_u32 %0, %0, 3, %1")
 DEF(add_lshl, "v_add_lshl_u32 %0, %0, %1, 3")
 DEF(or3, "v_or3_b32 %0, %0, %1, %2")
+// 64-bit register pairs: packed fp32 (two fp32 operations per lane and instruction), 64-bit shifts / moves
+#define DEF2(name, ASM)                                                                         \
+    __global__ __launch_bounds__(256) void k_##name(uint32_t* out, uint32_t seed) {             \
+        double a0 = threadIdx.x + seed, a1 = a0 * 3, a2 = a0 * 5, a3 = a0 * 7, a4 = a0 * 11, a5 = a0 * 13, a6 = a0 * 17, a7 = a0 * 19; \
+        double b = seed * 77 + 5, c = seed + 9;                                                 \
+        for (int i = 0; i < ITER; i++) {                                                        \
+            asm volatile(ASM "\n" : "+v"(a0) : "v"(b), "v"(c)); asm volatile(ASM "\n" : "+v"(a1) : "v"(b), "v"(c)); \
+            asm volatile(ASM "\n" : "+v"(a2) : "v"(b), "v"(c)); asm volatile(ASM "\n" : "+v"(a3) : "v"(b), "v"(c)); \
+            asm volatile(ASM "\n" : "+v"(a4) : "v"(b), "v"(c)); asm volatile(ASM "\n" : "+v"(a5) : "v"(b), "v"(c)); \
+            asm volatile(ASM "\n" : "+v"(a6) : "v"(b), "v"(c)); asm volatile(ASM "\n" : "+v"(a7) : "v"(b), "v"(c)); \
+        }                                                                                       \
+        out[blockIdx.x * blockDim.x + threadIdx.x] = (uint32_t)(a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7); \
+    }
+DEF2(pk_add_f32, "v_pk_add_f32 %0, %0, %1")
+DEF2(pk_mul_f32, "v_pk_mul_f32 %0, %0, %1")
+DEF2(pk_fma_f32, "v_pk_fma_f32 %0, %0, %1, %2")
+DEF2(pk_mov_b32, "v_pk_mov_b32 %0, %0, %1")
+DEF2(lshlrev_b64, "v_lshlrev_b64 %0, 3, %0")
+DEF(cvt_f32_ubyte0, "v_cvt_f32_ubyte0 %0, %0")
+DEF(cvt_i32_f32, "v_cvt_i32_f32 %0, %0")
+DEF(med3_f32_abs, "v_med3_f32 %0, |%0|, %1, %2")
+DEF(min3_f32_abs, "v_min3_f32 %0, |%0|, |%1|, |%2|")
+DEF(max3_f32, "v_max3_f32 %0, %0, %1, %2")
+DEF(add_f32_clamp, "v_add_f32_e64 %0, %0, %1 clamp")
+DEF(fma_f32_clamp, "v_fma_f32 %0, %0, %1, %2 clamp")
+DEF(mul_legacy, "v_mul_legacy_f32 %0, %0, %1")
+DEF(ldexp_f32, "v_ldexp_f32 %0, %0, %1")
+DEF(cvt_pk_i16_i32, "v_cvt_pk_i16_i32 %0, %0, %1")
+DEF(cvt_pk_u16_u32, "v_cvt_pk_u16_u32 %0, %0, %1")
+DEF(cvt_pknorm_i16, "v_cvt_pknorm_i16_f32 %0, %0, %1")
+DEF(sat_pk_u8_i16, "v_sat_pk_u8_i16 %0, %0")
+DEF(pk_sub_i16_clamp, "v_pk_sub_i16 %0, %0, %1 clamp")
+DEF(pk_sub_u16_clamp, "v_pk_sub_u16 %0, %0, %1 clamp")
+DEF(pk_add_u16_clamp, "v_pk_add_u16 %0, %0, %1 clamp")
+DEF(pk_max_u16, "v_pk_max_u16 %0, %0, %1")
+DEF(min_u16, "v_min_u16 %0, %0, %1")
+DEF(dot4_i32_i8, "v_dot4_i32_i8 %0, %0, %1, %2")
+DEF(msad_u8, "v_msad_u8 %0, %0, %1, %2")
+DEF(sad_u32, "v_sad_u32 %0, %0, %1, %2")
+DEF(min3_i16, "v_min3_i16 %0, %0, %1, %2")
+DEF(med3_i16, "v_med3_i16 %0, %0, %1, %2")
 int main() {
     uint32_t* d; hipMalloc(&d, 4 * 256 * 256 * 16);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -113,5 +154,7 @@ int main() {
     RUN(min_f32) RUN(max_f32) RUN(med3_f32) RUN(min3_f32) RUN(add_f32) RUN(add_f32_abs) RUN(sub_f32) RUN(mul_f32) RUN(cvt_f32_ubyte1) RUN(cvt_pk_u8_f32) RUN(cvt_u32_f32) RUN(cvt_f32_i32)
     RUN(cmp_eq_f32_cnd) RUN(cmp_eq_u32_cnd) RUN(cmp_sgpr_cnd) RUN(and_b32) RUN(or_b32) RUN(not_b32) RUN(min_i32) RUN(max_i32) RUN(lshlrev) RUN(lshrrev) RUN(sub_sdwa) RUN(and_sdwa) RUN(mov_b32) RUN(alignbit) RUN(fma_mix) RUN(subrev_f32_neg)
     RUN(sub_i32_clamp) RUN(add_i32_clamp) RUN(sub_u32_clamp) RUN(add_u32_e64) RUN(lshl_sdwa) RUN(med3_u32) RUN(max3_u32) RUN(add_i16_clamp) RUN(sub_co) RUN(subb_co) RUN(xor3) RUN(lshl_add) RUN(add_lshl) RUN(or3)
+    RUN(pk_add_f32) RUN(pk_mul_f32) RUN(pk_fma_f32) RUN(pk_mov_b32) RUN(lshlrev_b64) RUN(cvt_f32_ubyte0) RUN(cvt_i32_f32) RUN(med3_f32_abs) RUN(min3_f32_abs) RUN(max3_f32)
+    RUN(add_f32_clamp) RUN(fma_f32_clamp) RUN(mul_legacy) RUN(ldexp_f32) RUN(cvt_pk_i16_i32) RUN(cvt_pk_u16_u32) RUN(cvt_pknorm_i16) RUN(sat_pk_u8_i16) RUN(pk_sub_i16_clamp) RUN(pk_sub_u16_clamp) RUN(pk_add_u16_clamp) RUN(pk_max_u16) RUN(min_u16) RUN(dot4_i32_i8) RUN(msad_u8) RUN(sad_u32) RUN(min3_i16) RUN(med3_i16)
     return 0;
 }
