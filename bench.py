@@ -492,6 +492,40 @@ def main():
                 # the never-converging rate scaled by cap / mean updates
                 "step_frac_of_hbm_peak": bl * val / 1e9 / HBM_PEAK_GBS,
                 "frac_of_proportional_rate": val / (out["value"] * args.trials / max(mean_upd, 1e-9))}
+            # The same frames through TWO handles in a software pipeline (enqueue / finish, one stream each, call i finished right before
+            # call i + 2 is enqueued): what a double-buffering block does. The tail of a launch -- no workgroup left to dispatch while
+            # its last groups finish, ~0.9 ms of a 14 ms call -- then runs under the next call's first groups. Same bits, and the
+            # group-synchronous stop has to survive two sweep kernels sharing the GPU (fallback rounds reported).
+            d2 = LdpcDecoder(standard=capi.STANDARD_DVBS2, framesize=capi.FECFRAME_NORMAL, rate="C1_2", outputmode=capi.OM_MESSAGE,
+                             max_trials=args.trials, group_size=G, max_frames=nf, device=local)
+            hs = [d, d2]
+            bs = [b, torch.empty_like(b)]
+            rs = [r, torch.empty_like(r)]
+            sts = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+            torch.cuda.synchronize(dev)
+            fb0 = d.fallback_rounds + d2.fallback_rounds
+            ncalls = 12  # (the first and the last call of a run have nothing to overlap with: 12 calls keep that below 2 %)
+
+            def enq(i):
+                hs[i % 2].enqueue_device(x.data_ptr(), nf, bs[i % 2].data_ptr(), 0, rs[i % 2].data_ptr(), sts[i % 2].cuda_stream)
+
+            def pipe():
+                for i in range(ncalls):
+                    if i >= 2:
+                        hs[i % 2].finish()
+                    enq(i)
+                hs[0].finish(); hs[1].finish()
+
+            enq(0); enq(1); hs[0].finish(); hs[1].finish()
+            tp = timed(pipe, 1, 0, shard, dev)
+            valp = nf * ncalls / tp
+            configs["config2_awgn"]["pipelined"] = {
+                "what": "two handles, enqueue / finish on one stream each, call i finished right before call i + 2 is enqueued",
+                "value": valp, "unit": "frames/s", "calls": ncalls,
+                "frac_of_proportional_rate": valp / (out["value"] * args.trials / max(mean_upd, 1e-9)),
+                "same_results": bool(torch.equal(rs[0], rs[1]) and torch.equal(bs[0], bs[1])),
+                "fallback_rounds": d.fallback_rounds + d2.fallback_rounds - fb0}
+            d2.close()
             d.close(); del x
         if "config2_host" in extras:
             host, fb = host_entry(np, torch, capi, LdpcDecoder, T, dev, local, N, out_bytes, nf, args.trials, G, stream, steps2, (nf, 512))

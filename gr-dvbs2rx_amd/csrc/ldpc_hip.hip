@@ -157,7 +157,16 @@ LdpcDecoderHip::LdpcDecoderHip(const LdpcTableDesc* table, int out_bits_message,
     solo_ = !pr_ && !dense_ && !hz2_ && dmax_ <= 16 && pol_solo;
     if (const char* e = getenv("DVBS2_SOLO")) solo_ = !pr_ && !dense_ && !hz2_ && dmax_ <= 16 && atoi(e) != 0;
     if (timing_on) solo_ = false;
-    soft_bar_ = !pr_ && !dense_ && !solo_ && dmax_ >= 20 && sched_.conflict_layers == 0; // frame barriers in software (ldpc_kernel.hpp)
+    // frame barriers in software (ldpc_kernel.hpp): by rule where no layer has hazards; with hazard layers only for the tables listed in
+    // ldpc_policy_soft.inc (measured on two leases, tools/soft_sweep.py)
+    bool pol_soft = sched_.conflict_layers == 0;
+    {
+        static const char* const kSoft[] = {
+#include "ldpc_policy_soft.inc"
+        };
+        for (const char* n : kSoft) if (!strcmp(n, table->name)) pol_soft = true;
+    }
+    soft_bar_ = !pr_ && !dense_ && !solo_ && dmax_ >= 20 && pol_soft;
     if (const char* e = getenv("DVBS2_SOFT_BARRIER")) soft_bar_ = !pr_ && !dense_ && !solo_ && dmax_ >= 20 && atoi(e) != 0; // (built for the degree classes >= 20)
     if (hz2_ || timing_on) soft_bar_ = false;
     for (int i = 0; i < sched_.q; i++) {
@@ -189,7 +198,7 @@ LdpcDecoderHip::LdpcDecoderHip(const LdpcTableDesc* table, int out_bits_message,
         // (the degree class 32 without the heavy-hazard paths walks the near pair as a lane chain inside the outer blocks -- the
         // two-level lane chain of check_node_hazard: the pair additionally has to be oriented like a single-pair chain, bit 12)
         // (not in the 80-VGPR build -- same rule as where dense_ is set below --: the chain's state does not fit there, 76 -> 349 spilled registers)
-        const bool tlc_build = tlc_class(dmax_) && !hz2_ && !pr_ && !dense_here && !soft_bar_; // (kTlc<DMAX, HZ2> && !SOFT && MINW == 1 in the kernel)
+        const bool tlc_build = tlc_class(dmax_) && !hz2_ && !pr_ && !dense_here && (!soft_bar_ || DVBS2_TLC_SOFT); // (kTlc<DMAX, HZ2> && !SOFT && MINW == 1 in the kernel)
         if (tlc_build && two_level_on && L.block < 360 && L.block <= lane_chain_max && (nc_code == 4 || nc_code == 8) &&
             (sched_.N / 360) * kSvWords >= lane_chain_words(L.block)) {
             int best_a = -1, best_b = -1, d1 = 360, d2 = 360;
@@ -359,7 +368,7 @@ LdpcDecoderHip::LdpcDecoderHip(const LdpcTableDesc* table, int out_bits_message,
         const unsigned long long a = (unsigned long long)d_iters_, b = (unsigned long long)d_gsync_;
         int spin_max = kGroupSpinMax;
         if (const char* e = getenv("DVBS2_GROUP_SPIN_MAX")) spin_max = std::max(0, atoi(e)); // tests: 0 = a waiting member gives up at once (fallback path)
-        const uint32_t hd[kRecHeaderWords] = { (uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32), (uint32_t)G_, (uint32_t)spin_max, 0, 0 };
+        const uint32_t hd[kRecHeaderWords] = { (uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32), (uint32_t)G_, (uint32_t)spin_max, (uint32_t)(getenv("DVBS2_STAGGER") ? atoi(getenv("DVBS2_STAGGER")) : 0) /*experiments (DVBS2_EXP_STAGGER builds)*/, 0 };
         HIP_OK(hipMemcpy(d_recs_alloc_, hd, sizeof(hd), hipMemcpyHostToDevice));
     }
     if (const char* e = getenv("DVBS2_RESOLVE_ROUNDS")) resolve_rounds_ = std::max(0, std::min(8, atoi(e))); // tests: 0 forces the host-side leftover path

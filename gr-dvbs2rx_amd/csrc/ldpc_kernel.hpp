@@ -13,6 +13,10 @@
 #define DVBS2_FWALK 1 // float walk with four rows in flight in the plain lane chain of the degree class 8 (check_node_hazard)
 #endif
 
+#ifndef DVBS2_TLC_SOFT
+#define DVBS2_TLC_SOFT 0 // experiments: the two-level lane chain also in the builds with software frame barriers
+#endif
+
 namespace dvbs2 {
 
 // Thread mapping: a workgroup of 12 wavefronts decodes a PAIR of FECFRAMEs in lockstep; wavefronts 0-5 own
@@ -1270,7 +1274,7 @@ __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, con
 #define DVBS2_HAZ_CALL1(D, NCV, LRV, TLCV) { \
         if (layer0) check_node_hazard<D, NCV, true, false, false, HZ2, LRV, TLCV, (MINW == 1)>(lds_all, ent, jj, lb, work, block, block2, mw, nm, 0, nullptr, htab, hb_ctr, hb_epoch, hb_lane, hz_ph); else check_node_hazard<D, NCV, false, false, false, HZ2, LRV, TLCV, (MINW == 1)>(lds_all, ent, jj, lb, work, block, block2, mw, nm, 0, nullptr, htab, hb_ctr, hb_epoch, hb_lane, hz_ph); }
 #define DVBS2_HAZ_CALL(D, NCV) { if constexpr (D - 2 >= NCV) { \
-        if constexpr (kTlc<DMAX, HZ2> && !SOFT && MINW == 1 && (NCV == 4 || NCV == 8)) { if (block2 > 0 && htab != nullptr) DVBS2_HAZ_CALL1(D, NCV, (DMAX >= kTlcLowRegMinDmax), true) else DVBS2_HAZ_CALL1(D, NCV, (kLowReg<DMAX, HZ2>), false) } \
+        if constexpr (kTlc<DMAX, HZ2> && (!SOFT || DVBS2_TLC_SOFT) && MINW == 1 && (NCV == 4 || NCV == 8)) { if (block2 > 0 && htab != nullptr) DVBS2_HAZ_CALL1(D, NCV, (DMAX >= kTlcLowRegMinDmax), true) else DVBS2_HAZ_CALL1(D, NCV, (kLowReg<DMAX, HZ2>), false) } \
         else DVBS2_HAZ_CALL1(D, NCV, (kLowReg<DMAX, HZ2>), false) } }
 #define DVBS2_HAZ_CASE(D) case D: if constexpr (D >= 4 && D <= DMAX && D > DMAX - 8) { \
         if (nc == 2) DVBS2_HAZ_CALL((D >= 4 ? D : 4), 2) else if (nc == 4) DVBS2_HAZ_CALL((D >= 4 ? D : 4), 4) else { if constexpr (HZ2 && DMAX <= kMaxHazard12Dmax) { if (nc == 8) DVBS2_HAZ_CALL((D >= 4 ? D : 4), 8) else DVBS2_HAZ_CALL((D >= 4 ? D : 4), 12) } else DVBS2_HAZ_CALL((D >= 4 ? D : 4), 8) } } break;
@@ -1470,6 +1474,13 @@ __global__ __launch_bounds__(SOLO ? kSoloThreads : kThreads, SOLO ? 4 : MINW) vo
     int hb_epoch = 0;
     const int hb_lane = lane;
     __syncthreads();
+#ifdef DVBS2_EXP_STAGGER
+    // experiment: with software frame barriers nothing couples the two frames of a workgroup; the second one starts late (header
+    // word 6: units of ~4 k cycles), so that its ordered hazard steps fall into the first one's regular layers
+    if constexpr (SOFT) {
+        if (half == 1) { const uint32_t dl = (recs - kRecHeaderWords)[6]; for (uint32_t c = 0; c < dl; c++) __builtin_amdgcn_s_sleep(64); }
+    }
+#endif
     TSTAMP(tB); tm_load = tB - tA;
 
     // Messages go through a buffer descriptor based at this frame's records: the per-lane offset (row * 4, plus the
@@ -1667,7 +1678,7 @@ __global__ __launch_bounds__(SOLO ? kSoloThreads : kThreads, SOLO ? 4 : MINW) vo
             lds_u32_t* htab = ((hdr >> 12) & 1u) ? sv : nullptr; // lane-chain scratch: the sign-vector area is idle during a sweep
             const int block = (int)(hdr >> 16);
             int block2 = 0; // hazard layers: rows per outer block of the two-level walk (0: off)
-            if constexpr (HZ2 || (kTlc<DMAX, HZ2> && !SOFT && MINW == 1)) { if (block < kM) block2 = (int)wr[(size_t)i * RSW + 2]; }
+            if constexpr (HZ2 || (kTlc<DMAX, HZ2> && (!SOFT || DVBS2_TLC_SOFT) && MINW == 1)) { if (block < kM) block2 = (int)wr[(size_t)i * RSW + 2]; }
             const bool layer0 = (i == 0);
             const int mso = i * kLayerBytes; // scalar byte offset of this layer's message records
             TSTAMP(tA);

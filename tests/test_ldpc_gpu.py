@@ -268,6 +268,8 @@ def test_kernel_variant_policy(monkeypatch):
     assert name("S2_TABLE_B11", DVBS2_V2="1", DVBS2_SOLO="1") == "ldpc_layered_kernel<32, packed>"  # no one-frame build above 128 VGPRs
     assert name("S2X_TABLE_B21") == "ldpc_layered_kernel<32, soft>"   # long layers, no hazard layer: per-frame software barriers
     assert name("S2_TABLE_C10") == "ldpc_layered_kernel<28, hz2>"     # short 9/10: ten and twelve ordered entries per check
+    assert name("S2_TABLE_B9") == "ldpc_layered_kernel<24, soft>"     # 5/6 normal: hazard layers, but listed in ldpc_policy_soft.inc (measured)
+    assert name("S2_TABLE_B9", DVBS2_SOFT_BARRIER="0") == "ldpc_layered_kernel<24>"
     assert name("S2_TABLE_B4", DVBS2_PR="1") == "ldpc_layered_pr_kernel"
     assert name("S2_TABLE_B1", DVBS2_PR="1") == "ldpc_layered_pr_kernel<w1>"
 
@@ -551,6 +553,43 @@ def test_group_stop_needs_no_host_round_at_the_default_threshold():
     assert len(set(ret.tolist())) > 1 and (ret >= 0).all()
     assert dec.fallback_rounds == 0
     dec.close()
+
+
+def test_two_handles_pipelined_on_two_streams():
+    """What a double-buffering block does (bench.py, config2_awgn.pipelined): two handles, enqueue / finish on one
+    stream each, call i finished right before call i + 2 is enqueued, so two sweep kernels share the GPU most of the time. Converging
+    groups (the group-synchronous stop waits for co-resident members: workgroups of two launches are dispatched interleaved) must come
+    out like the reference's lockstep batches on every call, and no member may have given up waiting (fallback rounds stay zero)."""
+    import torch
+    table = "S2_TABLE_B4"
+    N, K, _, _ = T.ldpc_info(table)
+    nf = 2048
+    llrs = [T.llr_codeword_awgn(table, nf, 500 + i, amp=6, sigma=4.8)[0] for i in range(2)]
+    wants = [T.ref_ldpc_decode_parallel(table, x, 0, 50) if T.ref_ldpc() is not None else T.oracle_ldpc_decode(table, x[:64], 32, 50) for x in llrs]
+    decs = [LdpcDecoder(table=table, message_bits=K, group_size=32, max_frames=nf, max_trials=50, outputmode=capi.OM_MESSAGE) for _ in range(2)]
+    d_in = [torch.from_numpy(x).cuda() for x in llrs]
+    d_bits = [torch.zeros((nf, K // 8), dtype=torch.uint8, device="cuda") for _ in range(2)]
+    d_out = [torch.zeros((nf, N), dtype=torch.int8, device="cuda") for _ in range(2)]
+    d_ret = [torch.zeros(nf // 32, dtype=torch.int32, device="cuda") for _ in range(2)]
+    sts = [torch.cuda.Stream(), torch.cuda.Stream()]
+    torch.cuda.synchronize()
+    for i in range(12):
+        h = i % 2
+        if i >= 2:
+            decs[h].finish()
+            nchk = len(wants[h][1])
+            assert d_ret[h].cpu().tolist()[:nchk] == wants[h][1], (i, h)
+            assert np.array_equal(d_out[h][:32 * nchk].cpu().numpy(), wants[h][0][:32 * nchk]), (i, h)
+            assert np.array_equal(d_bits[h][:32 * nchk].cpu().numpy(), T.pack_bits(wants[h][0][:32 * nchk], K)), (i, h)
+            d_ret[h].zero_(); d_out[h].zero_(); torch.cuda.synchronize()
+        decs[h].enqueue_device(d_in[h].data_ptr(), nf, d_bits[h].data_ptr(), d_out[h].data_ptr(), d_ret[h].data_ptr(), sts[h].cuda_stream)
+    for h in range(2):
+        decs[h].finish()
+        assert d_ret[h].cpu().tolist()[:len(wants[h][1])] == wants[h][1]
+    assert len(set(wants[0][1])) > 1  # groups stop at different counts
+    assert decs[0].fallback_rounds == 0 and decs[1].fallback_rounds == 0
+    for d in decs:
+        d.close()
 
 
 def test_host_link_measurement_entry():

@@ -5,6 +5,8 @@
 #include <cstdint>
 #include <map>
 #include <vector>
+#include <chrono>
+#include <string>
 __global__ void k(uint32_t* out, int spin)
 {
     extern __shared__ uint8_t sm[];
@@ -16,13 +18,35 @@ __global__ void k(uint32_t* out, int spin)
     while (__builtin_readcyclecounter() - t0 < (uint64_t)spin) { }
     if ((threadIdx.x & 63) == 0) { out[(blockIdx.x * 16 + (threadIdx.x >> 6)) * 2] = hw; out[(blockIdx.x * 16 + (threadIdx.x >> 6)) * 2 + 1] = xcc; }
 }
+// the same with the occupancy capped at three waves per SIMD (the compiler pads the kernel's VGPR allocation to 136 .. 168): do two
+// 6-wave workgroups then land 3,3,3,3 -- is the dispatcher's placement resource-aware, or does the second workgroup not fit at all?
+// (amdgpu_waves_per_eu(3, 3) does NOT pad the allocation with this compiler: .amdhsa_next_free_vgpr stays at what the code uses; a
+// clobbered high register does)
+__global__ void k3(uint32_t* out, int spin)
+{
+    extern __shared__ uint8_t sm[];
+    asm volatile("v_mov_b32 v140, 0" ::: "v140");
+    uint32_t hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    sm[threadIdx.x] = (uint8_t)hw;
+    uint64_t t0 = __builtin_readcyclecounter();
+    while (__builtin_readcyclecounter() - t0 < (uint64_t)spin) { }
+    if ((threadIdx.x & 63) == 0) { out[(blockIdx.x * 16 + (threadIdx.x >> 6)) * 2] = hw; out[(blockIdx.x * 16 + (threadIdx.x >> 6)) * 2 + 1] = xcc; }
+}
 int main(int argc, char** argv)
 {
+    const bool cap3 = argc > 3 && atoi(argv[3]) != 0;
     const int waves = argc > 1 ? atoi(argv[1]) : 6, lds = argc > 2 ? atoi(argv[2]) : 75000, blocks = 512;
     uint32_t* d; (void)hipMalloc(&d, blocks * 16 * 2 * 4); (void)hipMemset(d, 0xff, blocks * 16 * 2 * 4);
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    hipLaunchKernelGGL(k, dim3(blocks), dim3(64 * waves), lds, 0, d, 2000000);
+    (void)hipFuncSetAttribute((const void*)k3, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    auto t0 = std::chrono::steady_clock::now();
+    if (cap3) hipLaunchKernelGGL(k3, dim3(blocks), dim3(64 * waves), lds, 0, d, 2000000);
+    else hipLaunchKernelGGL(k, dim3(blocks), dim3(64 * waves), lds, 0, d, 2000000);
     (void)hipDeviceSynchronize();
+    printf("%s: %.2f ms for %d workgroups spinning 2 M ticks (20 ms at 100 MHz) each\n", cap3 ? "capped at 3 waves per SIMD" : "plain",
+           std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), blocks);
     std::vector<uint32_t> h(blocks * 16 * 2); (void)hipMemcpy(h.data(), d, h.size() * 4, hipMemcpyDeviceToHost);
     std::map<uint32_t, std::vector<int>> per_cu; // key: xcc, se, sh, cu -> simd ids of resident waves with block id
     for (int b = 0; b < blocks; b++) for (int w = 0; w < waves; w++) {
