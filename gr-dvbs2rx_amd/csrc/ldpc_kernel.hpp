@@ -13,6 +13,17 @@
 #define DVBS2_FWALK 1 // float walk with four rows in flight in the plain lane chain of the degree class 8 (check_node_hazard)
 #endif
 
+// Lane-chain layers (check_node_hazard), round 4: the pair's LLR bytes read with the regular entries, and the float walk on absolute LDS
+// addresses. Largest check degree that gets them -- measured (interleaved A/B, whole tables): degree <= 8: B4 +0.7 %, 9/20 ... S2_TABLE_B3 +1.8 %,
+// B1 +1 %, B2 -0.6 %; degree class 12: 3/5 normal 0, 2/3 normal and T2 2/3 -4 % (register allocation of their one-frame builds) -- and the
+// degree-5..8 instantiations INSIDE the class-12 kernel cost its tables 3-7 % as well (S2X 99/180 ... S2X_TABLE_B4 -7 %), so the switch is the
+// kernel's class (CLASS8 = DMAX <= 8), not the check degree
+#ifndef DVBS2_EARLY_PAIR_MAXDEG
+#define DVBS2_EARLY_PAIR_MAXDEG 8
+#endif
+#ifndef DVBS2_WALK_ABS_MAXDEG
+#define DVBS2_WALK_ABS_MAXDEG 8
+#endif
 #ifndef DVBS2_TLC_SOFT
 #define DVBS2_TLC_SOFT 0 // experiments: the two-level lane chain also in the builds with software frame barriers
 #endif
@@ -725,7 +736,8 @@ constexpr int kHazardWalk = 15; // header code: too many hazard entries, fall ba
 template <int DEG, int NC, bool LAYER0, bool PR = false, bool LAST = false, bool TWO = false /*two-level walk compiled in*/,
           bool LR = false /*low-register form (see check_node_lr): regular entries keep one packed word, their addresses are computed twice*/,
           bool TLC = false /*two-level walk with the near pair as a LANE CHAIN (round 3), see below*/,
-          bool CHAINOK = true /*false: no lane chain in this build (the 80-VGPR build since round 4, see kLaneChainBuilt)*/>
+          bool CHAINOK = true /*false: no lane chain in this build (the 80-VGPR build since round 4, see kLaneChainBuilt)*/,
+          bool CLASS8 = false /*the kernel of the degree class <= 8: early pair reads, walk on absolute addresses (DVBS2_EARLY_PAIR_MAXDEG)*/>
 __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, const uint32_t* ent, int jj, int lb, bool work,
                                                   int block, int block2 /*two-level walk: rows per outer block, 0 = off*/, const uint32_t* mw, uint32_t* nm, int own_in, int* carry,
                                                   lds_u32_t* tab /*lane_chain_words(block) of LDS scratch when the layer is a lane chain*/,
@@ -740,6 +752,11 @@ __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, con
     constexpr int NAD = LR ? NC : DEG; // LR: only the ordered entries keep their addresses
     int ad[NAD], inp[LR ? NC : DEG], mg[LR ? NC : DEG];
     int pm[LR ? DEG : 1];  // LR: regular entry k keeps pm[k] (check_node_lr)
+    // Lane-chain layers of the low degree classes: the pair's two LLR bytes are read WITH the regular entries (one LDS round trip for all
+    // seven instead of three in a row on the wave that walks the chain afterwards). A value read here is used only by the rows for which
+    // no earlier row of this layer writes that bit: entry 0 of the rows below 360 - block, entry 1 of the heads.
+    constexpr bool kEarlyPair = CLASS8 && DEG <= DVBS2_EARLY_PAIR_MAXDEG && NC == 2 && !LR && !PR && CHAINOK && DEG <= DVBS2_FWALK_MAXDEG;
+    int Lh01[2] = { 0x80, 0x80 };
     int p0 = 0, p1 = 0;
     const int jjb = jj + lb, jjb360 = jjb - kM;
     int min0 = 127, min1 = 127, signs = 0;
@@ -776,6 +793,7 @@ __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, con
         }
 #pragma unroll
         for (int k = 0; k < DEG; k++) {
+            if (kEarlyPair && k < 2) Lh01[k] = lds_rd(ad[k]); // (see the lane chain below: issued with the regular reads, used only where still valid)
             if (k >= NC) { // regular entry
                 const int Lb = (OWN_REG && k == DEG - 2) ? own_in : (PREV_REG && k == DEG - 1) ? *carry : lds_rd(ad[k]);
                 const int mb = (int)((mw[k >> 2] >> (8 * (k & 3))) & 0xffu);
@@ -856,12 +874,12 @@ __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, con
         constexpr bool kTwoBarrier = LR || DEG <= 20;
         const bool orig0 = work && (kTwoBarrier ? jj + block < kM : jj < block); // entry 0 still holds its value from before the layer (every head is one: block <= 128)
         if (orig0) {
-            const int L0 = lds_rd(ad[0]);
+            const int L0 = kEarlyPair ? Lh01[0] : lds_rd(ad[0]);
             inp[0] = min(max(L0 - hmb[0], -128), 127);
             mg[0] = mag_raw(L0, hmb[0]);
         }
         if (head) {
-            const int L1 = lds_rd(ad[1]);
+            const int L1 = kEarlyPair ? Lh01[1] : lds_rd(ad[1]);
             inp[1] = min(max(L1 - hmb[1], -128), 127);
             mg[1] = mag_raw(L1, hmb[1]);
             int o0, o1;
@@ -886,6 +904,34 @@ __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, con
         DVBS2_PH(1); // chain heads + publishing
         lds_barrier();
         DVBS2_PH(3); // barrier
+        if constexpr (kFloatWalk && CLASS8 && DEG <= DVBS2_WALK_ABS_MAXDEG) { if (head) {
+            // absolute LDS addresses, ONE running address for the records and one for the log (through typed pointers the compiler kept
+            // eight offsets and added the array base at every access: four address instructions per step of a lone wave)
+            int ra = (int)(uint32_t)(size_t)(frec + jj + block), la = (int)(uint32_t)(size_t)(flog + jj + block);
+            const int rs = block * 16, ls = block * 4;
+            auto ld = [](int a) -> v4f32 { return *reinterpret_cast<const lds_v4f_t*>((size_t)(uint32_t)a); };
+            const int nsteps = (kM - 1) / block;
+            float c = (float)chained;
+            auto step = [&](const v4f32 rc) {
+                *reinterpret_cast<lds_f32_t*>((size_t)(uint32_t)la) = c; la += ls;
+                const float x = __builtin_fmaf(c, rc.x, rc.y);
+                const float w = vmed3_f32(x, -rc.z, rc.z);
+                const float f = w - vmed3_f32(w, -1.f, 1.f);
+                c = vmed3_f32(rc.w + f, 0.f, 255.f);
+            };
+            v4f32 q0 = ld(ra), q1 = ld(ra + rs), q2 = ld(ra + 2 * rs), q3 = ld(ra + 3 * rs);
+            ra += 4 * rs;
+            int k = 0;
+            for (; k + 4 <= nsteps; k += 4) {
+                step(q0); q0 = ld(ra); ra += rs;
+                step(q1); q1 = ld(ra); ra += rs;
+                step(q2); q2 = ld(ra); ra += rs;
+                step(q3); q3 = ld(ra); ra += rs;
+            }
+            if (k < nsteps) { step(q0); k++; }
+            if (k < nsteps) { step(q1); k++; }
+            if (k < nsteps) { step(q2); k++; }
+        } } else
         if constexpr (kFloatWalk) { if (head) {
             const lds_v4f_t* rp = frec + jj + block;
             lds_f32_t* lp = flog + jj + block;
@@ -1272,7 +1318,7 @@ __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, con
 // state made the compiler spill the regular entries of EVERY four- and eight-entry layer around it, 9/10 normal's multi-pair
 // layers went from 12-17 k to 25-34 k cycles.)
 #define DVBS2_HAZ_CALL1(D, NCV, LRV, TLCV) { \
-        if (layer0) check_node_hazard<D, NCV, true, false, false, HZ2, LRV, TLCV, (MINW == 1)>(lds_all, ent, jj, lb, work, block, block2, mw, nm, 0, nullptr, htab, hb_ctr, hb_epoch, hb_lane, hz_ph); else check_node_hazard<D, NCV, false, false, false, HZ2, LRV, TLCV, (MINW == 1)>(lds_all, ent, jj, lb, work, block, block2, mw, nm, 0, nullptr, htab, hb_ctr, hb_epoch, hb_lane, hz_ph); }
+        if (layer0) check_node_hazard<D, NCV, true, false, false, HZ2, LRV, TLCV, (MINW == 1), (DMAX <= 8)>(lds_all, ent, jj, lb, work, block, block2, mw, nm, 0, nullptr, htab, hb_ctr, hb_epoch, hb_lane, hz_ph); else check_node_hazard<D, NCV, false, false, false, HZ2, LRV, TLCV, (MINW == 1), (DMAX <= 8)>(lds_all, ent, jj, lb, work, block, block2, mw, nm, 0, nullptr, htab, hb_ctr, hb_epoch, hb_lane, hz_ph); }
 #define DVBS2_HAZ_CALL(D, NCV) { if constexpr (D - 2 >= NCV) { \
         if constexpr (kTlc<DMAX, HZ2> && (!SOFT || DVBS2_TLC_SOFT) && MINW == 1 && (NCV == 4 || NCV == 8)) { if (block2 > 0 && htab != nullptr) DVBS2_HAZ_CALL1(D, NCV, (DMAX >= kTlcLowRegMinDmax), true) else DVBS2_HAZ_CALL1(D, NCV, (kLowReg<DMAX, HZ2>), false) } \
         else DVBS2_HAZ_CALL1(D, NCV, (kLowReg<DMAX, HZ2>), false) } }
