@@ -30,6 +30,9 @@
 // workgroup then sat through the L2's acknowledgement of its stores at every layer boundary. Waiting first costs nothing (the prefetch
 // is a layer old) and leaves the stores a whole layer to complete; no register is added. Measured (interleaved A/B): 1/4 normal +7 %,
 // B4 +1 %, S2X 9/20 and 154/180 +1.2 %.
+#ifndef DVBS2_WAIT_RECORDS
+#define DVBS2_WAIT_RECORDS 0 // measured: B4 119.6 -> 115.9 k with it (the register allocation of the record double buffer moves: more scalar copies per layer); S2X 18/30 and others gain -- off
+#endif
 #ifndef DVBS2_WAIT_BEFORE_STORE
 #define DVBS2_WAIT_BEFORE_STORE 1
 #endif
@@ -1718,6 +1721,13 @@ __global__ __launch_bounds__(SOLO ? kSoloThreads : kThreads, SOLO ? 4 : MINW) vo
 #pragma unroll
         for (int k = 0; k < 2 * DMAX; k += PF) nent[k] = wr[4 + k];
         DVBS2_WAIT_VM0(); // (the first layer's messages: once per sweep, so that inside the loop no path has a load pending at a layer boundary)
+#if DVBS2_WAIT_RECORDS
+        // the same for the first layer's RECORD: with its scalar loads pending on the path into the loop the compiler waits for them at the
+        // first use of the header -- behind the next record's prefetch, which every iteration then waits for as soon as it has issued it
+        // (an empty asm statement that "uses" the loaded words: the compiler has to complete the loads in front of it; an explicit s_waitcnt
+        // alone does not hold them -- loads of constant memory are moved across it)
+        asm volatile("" : "+s"(nhdr), "+s"(ninfo), "+s"(nent[0]), "+s"(nent[2 * DMAX - PF]));
+#endif
         for (int i = 0; i < q; i++) {
             const uint32_t hdr = nhdr, info = ninfo;
             const bool npacked = (info >> 8) & 1u; const int ndeg = (int)(info & 0xffu);
