@@ -21,6 +21,10 @@
 #include <cstdio>
 #include <cstdlib>
 
+#ifndef DVBS2_PR_DEFER_STORE
+#define DVBS2_PR_DEFER_STORE 1
+#endif
+
 namespace dvbs2 {
 
 __host__ __device__ constexpr size_t pr_half_bytes(int K) { return ((size_t)K + kM + 15) / 16 * 16; }
@@ -306,6 +310,17 @@ __global__ __launch_bounds__(kThreads, 6) void ldpc_layered_pr_kernel(
         uint32_t nent[2 * DMAX];
 #pragma unroll
         for (int k = 0; k < 2 * DMAX; k++) nent[k] = recs[4 + k];
+        // The record a layer produces is STORED at the head of the next layer, behind an explicit s_waitcnt vmcnt(0) (see
+        // DVBS2_WAIT_BEFORE_STORE in ldpc_kernel.hpp: the compiler waits for the prefetched record with vmcnt(0) at the head of a layer,
+        // i.e. right behind the store the previous layer has just issued; stored here instead, everything that wait covers is a layer old).
+        // Here the wait cannot simply go in front of the store at the END of the layer: the layers of these tables are short and the
+        // prefetch issued at their head would not be back yet.
+        constexpr bool kDeferStore = DVBS2_PR_DEFER_STORE != 0;
+        uint32_t pend[RW];
+        int pend_i = 0;
+        bool pend_on = false; // uniform
+#pragma unroll
+        for (int w = 0; w < RW; w++) pend[w] = 0;
         for (int i = 0; i < q; i++) {
             const uint32_t hdr = nhdr;
             uint32_t ent[2 * DMAX];
@@ -335,6 +350,14 @@ __global__ __launch_bounds__(kThreads, 6) void ldpc_layered_pr_kernel(
                 for (int w = 0; w < MW; w++) { mw[w] = work ? pre1[w] : 0x80808080u; pre1[w] = pre2[w]; }
             }
             const int own_in = (int)(pre1[PW] >> 24); // top byte of record i+1 = P[i] (not used by the last layer)
+            if constexpr (kDeferStore) {
+                asm volatile("" ::: "memory"); __builtin_amdgcn_s_waitcnt(0x0f70); asm volatile("" ::: "memory"); // vmcnt(0), on every path
+                if (pend_on) {
+                    uint32_t* pp = msg_base + (size_t)pend_i * RW * kMsgStride;
+#pragma unroll
+                    for (int w = 0; w < RW; w++) pp[w * kMsgStride + row] = pend[w];
+                }
+            }
             if (work && i + 2 < q) {
 #pragma unroll
                 for (int w = 0; w < RW; w++) pre2[w] = mp[(2 * RW + w) * kMsgStride + row];
@@ -356,11 +379,26 @@ __global__ __launch_bounds__(kThreads, 6) void ldpc_layered_pr_kernel(
                 DVBS2_PRH_SWITCH
             }
             if (work) {
+                if constexpr (kDeferStore) {
+                    if constexpr (W1) pend[0] = have_y6 ? y6 : pr_w1_compress(nm);
+                    else {
+#pragma unroll
+                        for (int w = 0; w < MW; w++) pend[w] = nm[w];
+                    }
+                    pend_i = i; pend_on = true;
+                } else
                 if constexpr (W1) mp[jj] = have_y6 ? y6 : pr_w1_compress(nm);
                 else {
 #pragma unroll
                     for (int w = 0; w < MW; w++) mp[w * kMsgStride + jj] = nm[w];
                 }
+            }
+        }
+        if constexpr (kDeferStore) {
+            if (pend_on) { // the last layer's record
+                uint32_t* pp = msg_base + (size_t)pend_i * RW * kMsgStride;
+#pragma unroll
+                for (int w = 0; w < RW; w++) pp[w * kMsgStride + row] = pend[w];
             }
         }
         __syncthreads();
