@@ -30,6 +30,12 @@
 // workgroup then sat through the L2's acknowledgement of its stores at every layer boundary. Waiting first costs nothing (the prefetch
 // is a layer old) and leaves the stores a whole layer to complete; no register is added. Measured (interleaved A/B): 1/4 normal +7 %,
 // B4 +1 %, S2X 9/20 and 154/180 +1.2 %.
+#ifndef DVBS2_PREFETCH_AFTER_BARRIER_MAX_DMAX
+#define DVBS2_PREFETCH_AFTER_BARRIER_MAX_DMAX 8
+#endif
+#ifndef DVBS2_LDS_ONLY_BARRIER
+#define DVBS2_LDS_ONLY_BARRIER 0
+#endif
 #ifndef DVBS2_WAIT_RECORDS
 #define DVBS2_WAIT_RECORDS 0 // measured: B4 119.6 -> 115.9 k with it (the register allocation of the record double buffer moves: more scalar copies per layer); S2X 18/30 and others gain -- off
 #endif
@@ -104,7 +110,11 @@ __device__ __forceinline__ void frame_barrier(volatile lds_i32_t* ctr, int& epoc
 {
     // (Round 4, with no FLAT access left in the kernel: the barrier without the wait for outstanding vector memory operations that
     // __syncthreads() implies -- s_waitcnt lgkmcnt(0) + s_barrier -- measured again: +-0.3 % on every BASELINE table. Not used.)
+#if DVBS2_LDS_ONLY_BARRIER
+    if (!ctr) { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); return; } // (experiment: no wait for outstanding vector memory operations)
+#else
     if (!ctr) { __syncthreads(); return; } // hardware barrier of the workgroup (the default)
+#endif
     epoch += 6;
     asm volatile("" ::: "memory");
     if (lane == 0) __hip_atomic_fetch_add(const_cast<lds_i32_t*>(ctr), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1742,7 +1752,11 @@ __global__ __launch_bounds__(SOLO ? kSoloThreads : kThreads, SOLO ? 4 : MINW) vo
                 for (int k = 0; k < 2 * DMAX; k += PF) nent[k] = p[4 + k];
             };
             // a packed-node layer (bit 13) may issue these loads from inside the node; the others here
-            prefetch(0u);
+            // Degree classes up to DVBS2_PREFETCH_AFTER_BARRIER_MAX_DMAX issue them BEHIND the layer's barrier: in front of it the wave waits
+            // for them (lgkmcnt(0) of the barrier and of the first use of the header) as soon as it has issued them. Measured: B4 +0.7 %,
+            // 1/3 normal +1.5 %, S2X 9/20 +1.2 %, 1/4 normal +1.4 %; the classes 12-32 lose up to 5 % (S2X 100/180 ... S2X_TABLE_B16) -- class 8 only.
+            constexpr bool kPab = DMAX <= DVBS2_PREFETCH_AFTER_BARRIER_MAX_DMAX;
+            if constexpr (!kPab) prefetch(0u);
             const int deg = (int)(hdr & 0xffu) + 2;
             const int nc = (int)((hdr >> 8) & 0xfu);
             lds_u32_t* htab = ((hdr >> 12) & 1u) ? sv : nullptr; // lane-chain scratch: the sign-vector area is idle during a sweep
@@ -1753,6 +1767,7 @@ __global__ __launch_bounds__(SOLO ? kSoloThreads : kThreads, SOLO ? 4 : MINW) vo
             const int mso = i * kLayerBytes; // scalar byte offset of this layer's message records
             TSTAMP(tA);
             if (hdr & 0x8000u) lds_barrier();
+            if constexpr (kPab) { asm volatile("" ::: "memory"); prefetch(0u); }
             TSTAMP(tB); tm_bar += tB - tA;
             if (block >= kM) {
                 // regular layer: all 360 checks at once
