@@ -29,7 +29,7 @@
 // cannot count them -- and, left alone, places that wait at their first use, i.e. right AFTER the stores it has just issued: every wave of the
 // workgroup then sat through the L2's acknowledgement of its stores at every layer boundary. Waiting first costs nothing (the prefetch
 // is a layer old) and leaves the stores a whole layer to complete; no register is added. Measured (interleaved A/B): 1/4 normal +7 %,
-// B4 +1 %, S2X 9/20 and 154/180 +1.2 %.
+// B4 +3.6 %, 1/3 normal +8 %, 3/4 normal +3 % (23 tables, none loses); not in the software-barrier builds (S2X 154/180 -4 %).
 #ifndef DVBS2_PREFETCH_AFTER_BARRIER_MAX_DMAX
 #define DVBS2_PREFETCH_AFTER_BARRIER_MAX_DMAX 8
 #endif
@@ -37,7 +37,7 @@
 #define DVBS2_LDS_ONLY_BARRIER 0
 #endif
 #ifndef DVBS2_WAIT_RECORDS
-#define DVBS2_WAIT_RECORDS 0 // measured: B4 119.6 -> 115.9 k with it (the register allocation of the record double buffer moves: more scalar copies per layer); S2X 18/30 and others gain -- off
+#define DVBS2_WAIT_RECORDS 0 // measured: B4 119.6 -> 115.9 k with it (the register allocation of the record double buffer moves: more scalar copies per layer); S2X_TABLE_B8 and others gain -- off
 #endif
 #ifndef DVBS2_WAIT_BEFORE_STORE
 #define DVBS2_WAIT_BEFORE_STORE 1
@@ -1754,7 +1754,7 @@ __global__ __launch_bounds__(SOLO ? kSoloThreads : kThreads, SOLO ? 4 : MINW) vo
             // a packed-node layer (bit 13) may issue these loads from inside the node; the others here
             // Degree classes up to DVBS2_PREFETCH_AFTER_BARRIER_MAX_DMAX issue them BEHIND the layer's barrier: in front of it the wave waits
             // for them (lgkmcnt(0) of the barrier and of the first use of the header) as soon as it has issued them. Measured: B4 +0.7 %,
-            // 1/3 normal +1.5 %, S2X 9/20 +1.2 %, 1/4 normal +1.4 %; the classes 12-32 lose up to 5 % (S2X 100/180 ... S2X_TABLE_B16) -- class 8 only.
+            // 1/3 normal +1.5 %, S2X 9/20 +1.2 %, 1/4 normal +1.4 %; the classes 12-32 lose up to 5 % (S2X_TABLE_B16) -- class 8 only.
             constexpr bool kPab = DMAX <= DVBS2_PREFETCH_AFTER_BARRIER_MAX_DMAX;
             if constexpr (!kPab) prefetch(0u);
             const int deg = (int)(hdr & 0xffu) + 2;
