@@ -30,6 +30,12 @@
 // workgroup then sat through the L2's acknowledgement of its stores at every layer boundary. Waiting first costs nothing (the prefetch
 // is a layer old) and leaves the stores a whole layer to complete; no register is added. Measured (interleaved A/B): 1/4 normal +7 %,
 // B4 +3.6 %, 1/3 normal +8 %, 3/4 normal +3 % (23 tables, none loses); not in the software-barrier builds (S2X 154/180 -4 %).
+#ifndef DVBS2_PF_BIG
+#define DVBS2_PF_BIG 0 // measured (round 4, 17 tables of the classes 16-32): 3/4 normal +7 %, 8/9 +5 %, 9/10 +4 %, S2X 154/180 +9 %, the others +1...3 %, short 8/9 -0.7 %
+#endif
+#ifndef DVBS2_PF_SMALL
+#define DVBS2_PF_SMALL 1 // degree classes <= 12: the whole record double-buffered in scalar registers (0: none, experiment)
+#endif
 #ifndef DVBS2_PREFETCH_AFTER_BARRIER_MAX_DMAX
 #define DVBS2_PREFETCH_AFTER_BARRIER_MAX_DMAX 8
 #endif
@@ -1723,33 +1729,39 @@ __global__ __launch_bounds__(SOLO ? kSoloThreads : kThreads, SOLO ? 4 : MINW) vo
         // (an un-prefetched s_load at the head of every layer was a quarter of the sweep time). Small records are
         // buffered whole; for the large ones only every 8th dword is carried over -- enough to pull each cache
         // line of the next record into the scalar cache -- and the rest is loaded at the top of the layer.
-        constexpr int PF = DMAX <= 12 ? 1 : 8;
+        // DVBS2_PF_BIG: carried-over words of the large records. 8 (rounds 1-3): every 8th word. 0 (experiment, round 4): none -- the header
+        // words only; the ISA of the class 32 shows each carried word as its own `s_load_dword; s_waitcnt lgkmcnt(0); v_writelane` (no scalar
+        // register is free to hold it), eight exposed scalar round trips at every layer head, and the records of a table (5-7 KB) stay in
+        // the scalar cache anyway.
+        constexpr int PF = DMAX <= 12 ? (DVBS2_PF_SMALL != 0 ? DVBS2_PF_SMALL : 2 * DMAX) : (DVBS2_PF_BIG != 0 ? DVBS2_PF_BIG : 2 * DMAX);
         // the sweep reads the records of its own WAVE (check_node_v2): wrecs[(layer * 6 + wave) * RS]
         const uint32_t* wr = V2 ? wrecs + (size_t)wave_u * rec_stride_wave(DMAX) : recs; // builds without packed nodes read the per-layer records
         uint32_t nhdr = wr[0], ninfo = wr[1]; // word 1: message format of the NEXT layer for this wave (degree | packed << 8)
         uint32_t nent[2 * DMAX];
 #pragma unroll
-        for (int k = 0; k < 2 * DMAX; k += PF) nent[k] = wr[4 + k];
+        for (int k = 0; k < 2 * DMAX; k += PF) nent[k] = wr[4 + k]; // (PF = 2 DMAX: word 0 only, never used)
         DVBS2_WAIT_VM0(); // (the first layer's messages: once per sweep, so that inside the loop no path has a load pending at a layer boundary)
 #if DVBS2_WAIT_RECORDS
         // the same for the first layer's RECORD: with its scalar loads pending on the path into the loop the compiler waits for them at the
         // first use of the header -- behind the next record's prefetch, which every iteration then waits for as soon as it has issued it
         // (an empty asm statement that "uses" the loaded words: the compiler has to complete the loads in front of it; an explicit s_waitcnt
         // alone does not hold them -- loads of constant memory are moved across it)
-        asm volatile("" : "+s"(nhdr), "+s"(ninfo), "+s"(nent[0]), "+s"(nent[2 * DMAX - PF]));
+        asm volatile("" : "+s"(nhdr), "+s"(ninfo), "+s"(nent[0]));
 #endif
         for (int i = 0; i < q; i++) {
             const uint32_t hdr = nhdr, info = ninfo;
             const bool npacked = (info >> 8) & 1u; const int ndeg = (int)(info & 0xffu);
             uint32_t ent[2 * DMAX];
 #pragma unroll
-            for (int k = 0; k < 2 * DMAX; k++) ent[k] = (k % PF == 0) ? nent[k] : wr[(size_t)i * RSW + 4 + k];
+            for (int k = 0; k < 2 * DMAX; k++) ent[k] = (PF <= 2 * DMAX - 1 && k % PF == 0) ? nent[k] : wr[(size_t)i * RSW + 4 + k];
             const uint32_t* nrec = wr + (size_t)(i + 1 < q ? i + 1 : 0) * RSW;
             auto prefetch = [&](uint32_t after) {
                 const uint32_t* p = nrec; (void)after;
                 nhdr = p[0]; ninfo = p[1];
+                if constexpr (PF <= 2 * DMAX - 1) {
 #pragma unroll
-                for (int k = 0; k < 2 * DMAX; k += PF) nent[k] = p[4 + k];
+                    for (int k = 0; k < 2 * DMAX; k += PF) nent[k] = p[4 + k];
+                }
             };
             // a packed-node layer (bit 13) may issue these loads from inside the node; the others here
             // Degree classes up to DVBS2_PREFETCH_AFTER_BARRIER_MAX_DMAX issue them BEHIND the layer's barrier: in front of it the wave waits
