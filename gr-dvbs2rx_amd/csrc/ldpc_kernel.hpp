@@ -33,9 +33,9 @@
 #ifndef DVBS2_PF_BIG
 #define DVBS2_PF_BIG 0 // measured (round 4, 17 tables of the classes 16-32): 3/4 normal +7 %, 8/9 +5 %, 9/10 +4 %, S2X 154/180 +9 %, the others +1...3 %, short 8/9 -0.7 %
 #endif
-#ifndef DVBS2_PF_SMALL
-#define DVBS2_PF_SMALL 1 // degree classes <= 12: the whole record double-buffered in scalar registers (0: none, experiment)
-#endif
+#ifndef DVBS2_PF_SMALL_MAX_DMAX
+#define DVBS2_PF_SMALL_MAX_DMAX 8 // up to this degree class the whole record is double-buffered in scalar registers. Measured: class 8 loses 2-3 % without it
+#endif                            // (B4 119.7 -> 117.1 k), class 12 GAINS 1-3 % without it (3/5, 2/3 normal, S2X 11/20, T2 2/3, short 2/3; short 3/5 -0.7 %)
 #ifndef DVBS2_PREFETCH_AFTER_BARRIER_MAX_DMAX
 #define DVBS2_PREFETCH_AFTER_BARRIER_MAX_DMAX 8
 #endif
@@ -1733,7 +1733,7 @@ __global__ __launch_bounds__(SOLO ? kSoloThreads : kThreads, SOLO ? 4 : MINW) vo
         // words only; the ISA of the class 32 shows each carried word as its own `s_load_dword; s_waitcnt lgkmcnt(0); v_writelane` (no scalar
         // register is free to hold it), eight exposed scalar round trips at every layer head, and the records of a table (5-7 KB) stay in
         // the scalar cache anyway.
-        constexpr int PF = DMAX <= 12 ? (DVBS2_PF_SMALL != 0 ? DVBS2_PF_SMALL : 2 * DMAX) : (DVBS2_PF_BIG != 0 ? DVBS2_PF_BIG : 2 * DMAX);
+        constexpr int PF = DMAX <= DVBS2_PF_SMALL_MAX_DMAX ? 1 : (DVBS2_PF_BIG != 0 ? DVBS2_PF_BIG : 2 * DMAX);
         // the sweep reads the records of its own WAVE (check_node_v2): wrecs[(layer * 6 + wave) * RS]
         const uint32_t* wr = V2 ? wrecs + (size_t)wave_u * rec_stride_wave(DMAX) : recs; // builds without packed nodes read the per-layer records
         uint32_t nhdr = wr[0], ninfo = wr[1]; // word 1: message format of the NEXT layer for this wave (degree | packed << 8)

@@ -1,0 +1,5 @@
+#!/bin/bash
+O=gpurun_out/r4ah; mkdir -p $O
+DVBS2_LIB=$PWD/gr-dvbs2rx_amd/lib/libdvbs2_fec_hip_pfs0.so timeout 1500 python -m pytest tests/test_ldpc_gpu.py -m gpu -x -q -k "every_table_bit_exact and policy or near_threshold or never" 2>&1 | tail -1 > $O/test.txt; cat $O/test.txt
+bash tools/ab3.sh $O/ab.log "libdvbs2_fec_hip.so libdvbs2_fec_hip_pfs0.so" S2_TABLE_B4:50:4096 S2_TABLE_B1:50:4096 S2_TABLE_B2:50:4096 S2_TABLE_B3:50:4096 S2X_TABLE_B3:50:4096 S2X_TABLE_B11:50:4096 S2_TABLE_B5:50:4096 S2_TABLE_B6:50:4096 S2X_TABLE_B4:50:4096 S2X_TABLE_B22:50:4096 T2_TABLE_A3:50:4096 S2_TABLE_C5:25:16384 S2_TABLE_C6:25:16384 S2X_TABLE_C4:25:16384 T2_TABLE_B3:25:16384 > $O/ab_res.txt 2>&1
+cat $O/ab_res.txt
