@@ -262,14 +262,14 @@ def test_kernel_variant_policy(monkeypatch):
     assert name("S2_TABLE_C5") == "ldpc_layered_kernel<12, dense>"  # short 3/5: 16 of 18 layers are hazard layers
     assert name("S2_TABLE_C5", DVBS2_DENSE="0", DVBS2_V2="0", DVBS2_SOLO="0") == "ldpc_layered_kernel<12>"
     assert name("S2_TABLE_C1", DVBS2_PR="0", DVBS2_V2="0", DVBS2_SOLO="0") == "ldpc_layered_kernel<4>"  # degree <= 4: one message dword per check
-    assert name("S2_TABLE_B1") == "ldpc_layered_kernel<4>"
+    assert name("S2_TABLE_B1") == expect("S2_TABLE_B1", 4)
     assert name("S2_TABLE_B4", DVBS2_V2="1", DVBS2_SOLO="1") == "ldpc_layered_kernel<8, packed, solo>"
     assert name("S2_TABLE_B4", DVBS2_V2="0", DVBS2_SOLO="0") == "ldpc_layered_kernel<8>"
     assert name("S2_TABLE_B11", DVBS2_V2="1", DVBS2_SOLO="1") == "ldpc_layered_kernel<32, packed>"  # no one-frame build above 128 VGPRs
-    assert name("S2X_TABLE_B21") == "ldpc_layered_kernel<32, soft>"   # long layers, no hazard layer: per-frame software barriers
+    assert name("S2X_TABLE_B21") == ("ldpc_layered_kernel<32, packed, soft>" if pol["S2X_TABLE_B21"][0] else "ldpc_layered_kernel<32, soft>")  # long layers, no hazard layer: per-frame software barriers
     assert name("S2_TABLE_C10") == "ldpc_layered_kernel<28, hz2>"     # short 9/10: ten and twelve ordered entries per check
-    assert name("S2_TABLE_B9") == "ldpc_layered_kernel<24, soft>"     # 5/6 normal: hazard layers, but listed in ldpc_policy_soft.inc (measured)
-    assert name("S2_TABLE_B9", DVBS2_SOFT_BARRIER="0") == "ldpc_layered_kernel<24>"
+    assert name("S2_TABLE_B9") == expect("S2_TABLE_B9", 24)           # 5/6 normal: hazard layers -> hardware barriers (ldpc_policy_soft.inc lists the exceptions: none now)
+    assert name("S2_TABLE_B9", DVBS2_SOFT_BARRIER="1") == expect("S2_TABLE_B9", 24)[:-1] + ", soft>"
     assert name("S2_TABLE_B4", DVBS2_PR="1") == "ldpc_layered_pr_kernel"
     assert name("S2_TABLE_B1", DVBS2_PR="1") == "ldpc_layered_pr_kernel<w1>"
 
