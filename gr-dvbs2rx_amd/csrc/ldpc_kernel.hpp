@@ -43,7 +43,7 @@
 #define DVBS2_LDS_ONLY_BARRIER 0
 #endif
 #ifndef DVBS2_WAIT_RECORDS
-#define DVBS2_WAIT_RECORDS 0 // measured: B4 119.6 -> 115.9 k with it (the register allocation of the record double buffer moves: more scalar copies per layer); S2X_TABLE_B8 and others gain -- off
+#define DVBS2_WAIT_RECORDS 1 // first measured on the plain class-8 build: B4 119.6 -> 115.9 k (off); re-measured once B4 ran the packed one-frame build: B4 133.2 -> 134.5 k, 2/5 normal +0.7 %, 3/5 +1 %, the others +-0.5 % (on)
 #endif
 #ifndef DVBS2_WAIT_BEFORE_STORE
 #define DVBS2_WAIT_BEFORE_STORE 1
