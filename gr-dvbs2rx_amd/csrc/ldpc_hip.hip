@@ -145,8 +145,8 @@ LdpcDecoderHip::LdpcDecoderHip(const LdpcTableDesc* table, int out_bits_message,
     }
     bool two_level_on = true;
     if (const char* e = getenv("DVBS2_TWO_LEVEL")) two_level_on = atoi(e) != 0; // experiments / tests
-    int lane_chain_max = 128; // measured: gains up to block 64, flat to 128, slightly negative at 180 (three steps per layer)
-    if (const char* e = getenv("DVBS2_LANE_CHAIN_MAX")) lane_chain_max = std::min(180, atoi(e)); // experiments
+    int lane_chain_max = kChainMaxBlock; // rounds 2-3 (integer walk): gains up to block 64, flat to 128, slightly negative at 180; round 4 (float walk, packed chain): +0.2...1.6 % at 180
+    if (const char* e = getenv("DVBS2_LANE_CHAIN_MAX")) lane_chain_max = std::min(kChainMaxBlock, atoi(e)); // experiments
     // the 80-VGPR build (same rule as where dense_ is set below): no two-level lane chain (76 -> 349 spilled registers, round 3) and, since
     // round 4, no single-pair lane chain either -- with its tables addressed as LDS (typed pointers, ldpc_kernel.hpp) the chain code made that
     // build spill ten times as much (72 -> 725) and short 3/5 / 2/3 lost 30 %; its layers take the block scheme

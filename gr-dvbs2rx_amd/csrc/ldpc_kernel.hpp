@@ -84,7 +84,10 @@ __host__ __device__ constexpr int rec_stride_wave(int dmax) { return 2 * dmax + 
 constexpr int kRecHeaderWords = 8; // [0,1] iters base, [2,3] group words base, [4] group size, [5] polls before a waiting member gives up, rest unused
 // per frame: N LLR bytes, then the sign-vector area (syndrome test; scratch of the ordered hazard phases during a sweep:
 // at least kChainScratchWords dwords, which is what short frames get instead of their small sign-vector area), then 8 flag words
-constexpr int kChainMaxBlock = 128;                                             // largest block walked as a register chain
+#ifndef DVBS2_CHAIN_MAX_BLOCK
+#define DVBS2_CHAIN_MAX_BLOCK 180 // round 4: 128 -> 180 (blocks 129..180 are three-step block-scheme layers otherwise): 3/4 normal +1.6 %, 3/5 +1.3 %, B4 / 2/5 normal +0.4 %
+#endif
+constexpr int kChainMaxBlock = DVBS2_CHAIN_MAX_BLOCK;                                             // largest block walked as a register chain
 constexpr int kChainScratchWords = (kM + kChainMaxBlock) * 5 + 4;               // (360 + block) x (16-byte record + 4-byte log) + 16 bytes: the records are 16-byte aligned and the area starts at N, which is 8 mod 16 for short frames
 __host__ __device__ constexpr int sv_area_words(int N) { return (N / kM) * kSvWords > kChainScratchWords ? (N / kM) * kSvWords : kChainScratchWords; }
 __host__ __device__ constexpr size_t half_lds_bytes(int N) { return ((size_t)N + (size_t)sv_area_words(N) * 4 + 32 + 15) / 16 * 16; }
