@@ -1,6 +1,7 @@
 // c_api.hip -- extern "C" boundary (include/dvbs2_fec_hip.h). No exceptions leave this file.
 #include "../../include/dvbs2_fec_hip.h"
 #include <hip/hip_runtime.h>
+#include <cstdint>
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -42,7 +43,32 @@ struct dvbs2_ldpc {
     hipStream_t copy_stream = nullptr;
     hipEvent_t in_ready[LdpcDecoderHip::kSlots] = {};
     int device = 0;
+    // experiment / test knobs of the host entry, read ONCE when the handle is created (no getenv per decode call)
+    std::string host_plan;      // DVBS2_HOST_PLAN: comma list of chunk sizes, the last one repeats
+    int host_chunk = 0;         // DVBS2_HOST_CHUNK: one chunk size for the whole call (0: the measured plan)
+    int host_copy_stream = -1;  // DVBS2_HOST_COPY_STREAM: 0 / 1 force the copies off / onto the copy stream (-1: by kind of input buffer)
 };
+
+// Is [p, p + bytes) ONE page-locked host range the copy engine can address (hipHostMalloc'ed, or registered with dvbs2_host_register /
+// hipHostRegister)? Decided from the runtime's own record of the allocation that holds p -- its start and size
+// (HIP_POINTER_ATTRIBUTE_RANGE_START_ADDR / RANGE_SIZE) must cover the last byte -- so two registrations with a pageable hole between
+// them are not mistaken for one. When the runtime cannot answer, the range counts as pageable: the call then stages through the
+// handle's own pinned buffers, which is always correct.
+static bool host_range_page_locked(const void* p, size_t bytes)
+{
+    if (!p || !bytes) return false;
+    hipPointerAttribute_t a{};
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; } // an ordinary pageable pointer: not an error
+    if (a.type != hipMemoryTypeHost) return false;
+    void* start = nullptr; size_t size = 0;
+    if (hipPointerGetAttribute(&start, HIP_POINTER_ATTRIBUTE_RANGE_START_ADDR, const_cast<void*>(p)) != hipSuccess ||
+        hipPointerGetAttribute(&size, HIP_POINTER_ATTRIBUTE_RANGE_SIZE, const_cast<void*>(p)) != hipSuccess || !start || !size) {
+        (void)hipGetLastError();
+        return false;
+    }
+    const char* lo = (const char*)start; const char* q = (const char*)p;
+    return q >= lo && (size_t)(q - lo) + bytes <= size;
+}
 
 extern "C" {
 
@@ -61,6 +87,8 @@ int dvbs2_host_register(void* p, size_t bytes)
     HCHK(hipHostRegister(p, bytes, hipHostRegisterDefault));
     return DVBS2_OK;
 }
+
+int dvbs2_host_is_page_locked(const void* p, size_t bytes) { return host_range_page_locked(p, bytes) ? 1 : 0; }
 
 int dvbs2_host_unregister(void* p)
 {
@@ -135,6 +163,9 @@ static int ldpc_make(dvbs2_ldpc_t** h, const LdpcTableDesc* t, int message_bits,
     dvbs2_ldpc* o = new (std::nothrow) dvbs2_ldpc();
     if (!o) return fail(DVBS2_EDEVICE, "out of memory");
     o->device = device;
+    if (const char* e = getenv("DVBS2_HOST_PLAN")) o->host_plan = e;
+    if (const char* e = getenv("DVBS2_HOST_CHUNK")) o->host_chunk = std::max(2, atoi(e));
+    if (const char* e = getenv("DVBS2_HOST_COPY_STREAM")) o->host_copy_stream = atoi(e) != 0 ? 1 : 0;
     o->dec = new (std::nothrow) LdpcDecoderHip(t, message_bits, G, max_frames, device);
     if (!o->dec || !o->dec->ok()) {
         std::string m = o->dec ? o->dec->error() : "out of memory";
@@ -185,10 +216,13 @@ int dvbs2_ldpc_params(const dvbs2_ldpc_t* h, int* n, int* table_k, int* message_
     return DVBS2_OK;
 }
 
-static int ldpc_check_args(dvbs2_ldpc_t* h, const void* in, int n_frames, int max_trials, int out_mode, const void* bits)
+static int ldpc_check_args(dvbs2_ldpc_t* h, const void* in, int n_frames, int max_trials, int out_mode, const void* bits,
+                           const void* d_llr_out = nullptr, bool device_pointers = false)
 {
     if (!h) return fail(DVBS2_EINVAL, "null handle");
     if (n_frames < 0 || max_trials <= 0 || (n_frames && (!in || !bits))) return fail(DVBS2_EINVAL, "bad argument");
+    // the kernels move LLRs with 8-byte loads and stores (include/dvbs2_fec_hip.h): a misaligned device pointer would be a GPU memory fault
+    if (device_pointers && ((((uintptr_t)in) | ((uintptr_t)d_llr_out)) & 7u)) return fail(DVBS2_EINVAL, "d_llr_in / d_llr_out must be 8-byte aligned");
     if (out_mode != DVBS2_OM_CODEWORD && out_mode != DVBS2_OM_MESSAGE) return fail(DVBS2_EINVAL, "bad out_mode");
     if (n_frames > h->dec->max_frames()) return fail(DVBS2_ESIZE, "n_frames exceeds max_frames");
     return DVBS2_OK;
@@ -198,7 +232,7 @@ int dvbs2_ldpc_decode_device(dvbs2_ldpc_t* h, const int8_t* d_llr_in, int n_fram
                              uint8_t* d_bits_out, int8_t* d_llr_out, int32_t* d_ret, void* stream)
 {
     API_TRY
-    if (int rc = ldpc_check_args(h, d_llr_in, n_frames, max_trials, out_mode, d_bits_out)) return rc;
+    if (int rc = ldpc_check_args(h, d_llr_in, n_frames, max_trials, out_mode, d_bits_out, d_llr_out, true)) return rc;
     if (h->dec->decode_device(d_llr_in, n_frames, max_trials, out_mode, d_bits_out, d_llr_out, d_ret, (hipStream_t)stream))
         return fail(DVBS2_EDEVICE, h->dec->error());
     return DVBS2_OK;
@@ -209,7 +243,7 @@ int dvbs2_ldpc_enqueue_device(dvbs2_ldpc_t* h, const int8_t* d_llr_in, int n_fra
                               uint8_t* d_bits_out, int8_t* d_llr_out, int32_t* d_ret, void* stream)
 {
     API_TRY
-    if (int rc = ldpc_check_args(h, d_llr_in, n_frames, max_trials, out_mode, d_bits_out)) return rc;
+    if (int rc = ldpc_check_args(h, d_llr_in, n_frames, max_trials, out_mode, d_bits_out, d_llr_out, true)) return rc;
     if (h->dec->enqueue(d_llr_in, n_frames, max_trials, out_mode, d_bits_out, d_llr_out, d_ret, (hipStream_t)stream, 0, 0))
         return fail(DVBS2_EDEVICE, h->dec->error());
     return DVBS2_OK;
@@ -246,22 +280,8 @@ int dvbs2_ldpc_decode(dvbs2_ldpc_t* h, const int8_t* llr_in, int n_frames, int m
     // Results land where the DMA engine can write them: straight in the caller's buffer when it is page-locked (hipHostMalloc'ed, or
     // registered once with dvbs2_host_register -- what a block does with its item buffers), else in a pinned buffer of the handle
     // that is copied out when the chunk has finished.
-    // (the WHOLE range has to be one page-locked allocation / registration: first and last byte page-locked is not enough when two
-    // registrations leave a pageable hole between them -- the range of the allocation that holds the first byte must cover the last)
-    auto page_locked = [](const void* p, size_t bytes) {
-        if (!p || !bytes) return false;
-        hipPointerAttribute_t a0{}, a1{};
-        if (hipPointerGetAttributes(&a0, p) != hipSuccess || hipPointerGetAttributes(&a1, (const char*)p + bytes - 1) != hipSuccess) {
-            (void)hipGetLastError(); // an ordinary pageable pointer: not an error of this call
-            return false;
-        }
-        if (a0.type != hipMemoryTypeHost || a1.type != hipMemoryTypeHost) return false;
-        // one registration / allocation maps to one contiguous range of device addresses: the two ends must be bytes - 1 apart there too
-        // (two registrations with a pageable hole between them are two unrelated mappings)
-        if (a0.devicePointer && a1.devicePointer)
-            return (size_t)((const char*)a1.devicePointer - (const char*)a0.devicePointer) == bytes - 1;
-        return true;
-    };
+    // (the WHOLE range has to lie inside one page-locked allocation / registration: host_range_page_locked)
+    auto page_locked = [](const void* p, size_t bytes) { return host_range_page_locked(p, bytes); };
     const size_t n_groups = ((size_t)n_frames + G - 1) / G;
     uint8_t* bits_land = page_locked(bits_out, (size_t)n_frames * out_bytes) ? bits_out : nullptr;
     int8_t* llr_land = page_locked(llr_out, (size_t)n_frames * N) ? llr_out : nullptr;
@@ -282,30 +302,32 @@ int dvbs2_ldpc_decode(dvbs2_ldpc_t* h, const int8_t* llr_in, int n_frames, int m
     // little output is left to fetch when the decode ends.
     std::vector<std::pair<int, int>> plan;
     auto round_unit = [&](int x) { return std::max(unit, (x + unit - 1) / unit * unit); };
-    if (const char* e = getenv("DVBS2_HOST_PLAN")) { // experiments: comma list of chunk sizes, the last one repeats
+    if (!h->host_plan.empty()) { // experiments: comma list of chunk sizes, the last one repeats
         int f0 = 0, last = 512;
-        for (const char* q = e; f0 < n_frames;) {
+        for (const char* q = h->host_plan.c_str(); f0 < n_frames;) {
             if (*q) { last = std::max(2, atoi(q)); while (*q && *q != ',') q++; if (*q == ',') q++; }
             const int nf = std::min(round_unit(last), n_frames - f0);
             plan.push_back({ f0, nf }); f0 += nf;
         }
-    } else if (in_locked && n_frames > 1024 && !getenv("DVBS2_HOST_CHUNK")) {
+    } else if (in_locked && n_frames > 1024 && !h->host_chunk) {
         // measured (MI355X, 4096 frames of table B4, tools/host_entry_ab.py): 512 | 3072 | 512 -> 97.3 % of the resident rate, 512 | 3584
         // 97.3 %, 512 | 1536 | 1536 | 512 96.7 %, eight chunks of 512 93.6 %, four of 1024 95.0 %
-        const int b1 = round_unit(512);                                   // every boundary is a multiple of `unit` (frame_base of enqueue())
-        const int b2 = std::max(b1, (n_frames - 512) / unit * unit);
+        // every boundary is a multiple of `unit` (frame_base of enqueue()) and none lies past the call's last frame (a group size above
+        // 512 -- or an odd one above 256 -- makes `unit` larger than the first chunk: ADVICE r4)
+        const int b1 = std::min(round_unit(512), n_frames);
+        const int b2 = std::min(std::max(b1, (n_frames - 512) / unit * unit), n_frames);
         const int bounds[4] = { 0, b1, b2, n_frames };
         for (int k = 0; k < 3; k++) if (bounds[k + 1] > bounds[k]) plan.push_back({ bounds[k], bounds[k + 1] - bounds[k] });
     } else {
         // pageable input (measured as above): 512, then chunks of 1024 -> 96.0-96.5 %; eight equal chunks of 512 95.0-95.4 %
         int first = 512, chunk = std::max(1024, (n_frames + 7) / 8);
-        if (const char* e = getenv("DVBS2_HOST_CHUNK")) first = chunk = std::max(2, atoi(e)); // experiments, tests
+        if (h->host_chunk) first = chunk = h->host_chunk; // experiments, tests
         first = round_unit(first); chunk = round_unit(chunk);
         for (int f0 = 0; f0 < n_frames;) { const int nf = std::min(f0 ? chunk : first, n_frames - f0); plan.push_back({ f0, nf }); f0 += nf; }
     }
     const int n_chunks = (int)plan.size();
     bool use_copy_stream = in_locked;
-    if (const char* e = getenv("DVBS2_HOST_COPY_STREAM")) use_copy_stream = atoi(e) != 0; // experiments
+    if (h->host_copy_stream >= 0) use_copy_stream = h->host_copy_stream != 0; // experiments
     auto copy_out = [&](int c) -> int {
         const int f0 = plan[c].first, nf = plan[c].second;
         hipStream_t st = h->stream[c % LdpcDecoderHip::kSlots];
@@ -847,6 +869,7 @@ int dvbs2_chain_enqueue_llr_device(dvbs2_chain_t* h, const int8_t* d_llr, int n_
     if (h->pending) return fail(DVBS2_EINVAL, "previous call not finished");
     if (n_frames > h->max_frames) return fail(DVBS2_ESIZE, "n_frames exceeds max_frames");
     if (n_frames < 0 || max_trials <= 0 || (n_frames && (!d_llr || !d_msg))) return fail(DVBS2_EINVAL, "bad argument");
+    if (((uintptr_t)d_llr) & 7u) return fail(DVBS2_EINVAL, "d_llr must be 8-byte aligned"); // (8-byte loads: include/dvbs2_fec_hip.h)
     if (n_frames == 0) return DVBS2_OK;
     return chain_enqueue_tail(h, d_llr, nullptr, n_frames, max_trials, d_msg, d_ldpc_ret, d_bch_corr, stream);
     API_CATCH

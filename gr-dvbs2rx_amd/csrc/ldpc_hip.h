@@ -96,7 +96,7 @@ private:
     int* d_iters_ = nullptr;      // per frame: updates done
     int* d_good_ = nullptr;       // per frame: syndrome satisfied at the current state
     int* d_target_ = nullptr;     // per frame: updates to reach in a resume pass
-    int* d_gsync_ = nullptr;      // {arrive, lastbad} per group: group-synchronous stop inside the first pass (ldpc_kernel.hpp, group_decide)
+    int* d_gsync_ = nullptr;      // one status word per frame: group-synchronous stop inside the first pass (ldpc_kernel.hpp, group_decide)
     bool gsync_on_ = false;
     int* d_flag_ = nullptr;       // [slot] = number of unresolved groups
     int* h_flag_ = nullptr;       // pinned, [slot]

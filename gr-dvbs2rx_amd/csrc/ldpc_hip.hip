@@ -95,6 +95,10 @@ LdpcDecoderHip::LdpcDecoderHip(const LdpcTableDesc* table, int out_bits_message,
     if (!compile_ldpc_schedule(table, &sched_)) { err_ = "unknown or inconsistent LDPC table"; return; }
     if (G_ < 1 || max_frames_ < 1 || max_frames_ > 65535) { err_ = "bad group_size/max_frames (max_frames 1..65535: frames are one launch dimension)"; return; }
     if (out_bits_message_ <= 0 || out_bits_message_ > sched_.N || out_bits_message_ % 8) { err_ = "bad message length"; return; }
+    if (getenv("DVBS2_EXP_NOHAZ")) { // timing-only bound (wrong results): every layer runs as a regular layer
+        for (LdpcLayer& L : sched_.layers) { L.block = 360; L.n_conflict = 0; }
+        sched_.conflict_layers = 0;
+    }
     int degmax = 0, degmin = 1000;
     for (const LdpcLayer& L : sched_.layers) { degmax = std::max(degmax, L.cnt + 2); degmin = std::min(degmin, L.cnt + 2); }
     if (degmax > 32) { err_ = "check degree > 32 unsupported"; return; }
@@ -170,6 +174,8 @@ LdpcDecoderHip::LdpcDecoderHip(const LdpcTableDesc* table, int out_bits_message,
     soft_bar_ = !pr_ && !dense_ && !solo_ && dmax_ >= 20 && pol_soft;
     if (const char* e = getenv("DVBS2_SOFT_BARRIER")) soft_bar_ = !pr_ && !dense_ && !solo_ && dmax_ >= 20 && atoi(e) != 0; // (built for the degree classes >= 20)
     if (hz2_ || timing_on) soft_bar_ = false;
+    std::vector<std::vector<int>> layer_order(sched_.q); // record order of every layer's entries (ordered entries first, host-oriented pairs)
+    std::vector<int> layer_nc(sched_.q, 0);              // ordered entries the kernel handles in the layer's ordered phase (2, 4, 8, 12; kHazardWalk)
     for (int i = 0; i < sched_.q; i++) {
         const LdpcLayer& L = sched_.layers[i];
         uint32_t nc_code = 0;
@@ -238,6 +244,8 @@ LdpcDecoderHip::LdpcDecoderHip(const LdpcTableDesc* table, int out_bits_message,
                 for (int k = 0; k < L.n_conflict; k++) if (k != best_a && k != best_b) order[n++] = k;
             }
         }
+        layer_order[i].assign(order, order + L.cnt + 2);
+        layer_nc[i] = (int)nc_code;
         hr[(size_t)i * RS] = L.cnt | (nc_code << 8) | (chain << 12) | ((uint32_t)L.sync_before << 15) | ((uint32_t)L.block << 16);
         hr[(size_t)i * RS + 2] = block2;
         for (int k = 0; k < L.cnt + 2; k++) {
@@ -277,6 +285,8 @@ LdpcDecoderHip::LdpcDecoderHip(const LdpcTableDesc* table, int out_bits_message,
     // single-pair hazard layers walked by the packed register chain (check_node_chain_v2): block <= kChainMaxBlock, the pair are
     // the first two entries (schedule compiler), and on every wave the mixed regular entries fit the fix slots after the pair's
     std::vector<char> chain_v2_layer(sched_.q, 0), chain_order(sched_.q, 0);
+    bool v2p_on = true; // hazard layers with the packed first / last phase (classes from DVBS2_V2P_MIN_DMAX up); DVBS2_V2P=0: experiments, tests
+    if (const char* e = getenv("DVBS2_V2P")) v2p_on = atoi(e) != 0;
     chain_plain_ = false; // plain build + packed chain node (ldpc_kernel.hpp, CHAIN): measured slower, not built (kChainBuilt); experiments only
     if (const char* e = getenv("DVBS2_CHAIN_PLAIN")) chain_plain_ = !pr_ && !dense_ && !v2 && dmax_ <= 16 && atoi(e) != 0;
     bool chain_v2 = (v2 || chain_plain_) && dmax_ <= 16; // the packed chain node is only built for the low degree classes
@@ -306,15 +316,20 @@ LdpcDecoderHip::LdpcDecoderHip(const LdpcTableDesc* table, int out_bits_message,
             std::copy(hr.begin() + (size_t)i * RS, hr.begin() + (size_t)(i + 1) * RS, rec);
             if (i == 0) continue;
             const bool chain2 = L.block < 360 && chain_v2_layer[i];
-            if (L.block < 360 ? !chain2 : !v2) continue;
+            // hazard layers of the packed builds whose ordered phase is the generic one (check_node_hazard<..., V2P>, ldpc_kernel.hpp): the NC
+            // ordered entries keep their record order in the first fix slots, the mixed regular entries follow; dmax / 2 fix slots in all
+            const int ncv = layer_nc[i];
+            const bool v2p = v2 && v2p_on && v2p_class(dmax_) && L.block < 360 && !chain2 && (ncv == 2 || ncv == 4 || ncv == 8) && (int)L.cnt >= ncv;
+            if (L.block < 360 ? !(chain2 || v2p) : !v2) continue;
             const int lo = 64 * w, hi = std::min(64 * w + 63, 359);
             std::vector<int> mixed, plain;
             auto is_mixed = [&](int k) { const int thr = 360 - (int)sched_.entries[L.entry_off + k].rot; return lo < thr && thr <= hi; };
-            for (int k = chain2 ? 2 : 0; k < L.cnt; k++) (is_mixed(k) ? mixed : plain).push_back(k);
-            const int nfix = std::min(dmax_ / 4, (int)L.cnt);
+            if (v2p) { for (int k = ncv; k < L.cnt; k++) { const int e = layer_order[i][k]; (is_mixed(e) ? mixed : plain).push_back(e); } }
+            else for (int k = chain2 ? 2 : 0; k < L.cnt; k++) (is_mixed(k) ? mixed : plain).push_back(k);
+            const int nfix = v2p ? std::min(dmax_ / 2, (int)L.cnt) - ncv : std::min(dmax_ / 4, (int)L.cnt);
             if (!chain2 && (int)mixed.size() > nfix) continue; // (a chain layer was checked for every wave beforehand)
             std::fill(rec + 4, rec + RSW, 0u);
-            rec[0] = hr[(size_t)i * RS] | (1u << 13);
+            rec[0] = hr[(size_t)i * RS] | (1u << 13) | (v2p ? 1u << 14 : 0u);
             int slot = 0;
             auto put = [&](int k, bool is_mixed) {
                 const LdpcEntry& e = sched_.entries[L.entry_off + k];
@@ -334,6 +349,7 @@ LdpcDecoderHip::LdpcDecoderHip(const LdpcTableDesc* table, int out_bits_message,
                 const int kx = chain_order[i] ? 1 : 0;
                 put(kx, is_mixed(kx)); put(1 - kx, is_mixed(1 - kx));
             }
+            if (v2p) for (int k = 0; k < ncv; k++) { const int e = layer_order[i][k]; put(e, is_mixed(e)); } // ordered entries, in the per-layer record's order
             for (int k : mixed) put(k, true);
             for (int k : plain) put(k, false);
             put(L.cnt, false);     // own parity (rot 0)
@@ -364,7 +380,7 @@ LdpcDecoderHip::LdpcDecoderHip(const LdpcTableDesc* table, int out_bits_message,
     gsync_on_ = G_ <= 64;
     if (const char* e = getenv("DVBS2_GROUP_SYNC")) gsync_on_ = atoi(e) != 0 && G_ <= 64;
     if (gsync_on_) {
-        HIP_OK(hipMalloc(&d_gsync_, (size_t)(max_frames_ / G_ + 2) * 8));
+        HIP_OK(hipMalloc(&d_gsync_, (size_t)(max_frames_ + 64) * 4)); // one status word per frame (group_decide)
         resolve_rounds_ = 0;
         const unsigned long long a = (unsigned long long)d_iters_, b = (unsigned long long)d_gsync_;
         int spin_max = kGroupSpinMax;
@@ -383,12 +399,22 @@ LdpcDecoderHip::LdpcDecoderHip(const LdpcTableDesc* table, int out_bits_message,
         // complementary wave patterns through them, whichever launch (handle, stream) they belong to. With one array per handle two
         // pipelined handles both chose pattern 0 on every CU: 4,4,2,2 working waves per SIMD instead of 3,3,3,3 and the operating point
         // through two handles fell from 0.92 to 0.71 of the proportional rate (round 4). Allocated once per device, never freed.
+        // Keyed by the device this constructor actually runs on (hipGetDevice behind the guard), one entry per device ever seen; the
+        // array is zeroed BEFORE its pointer is published. The counts survive the handles (a kernel gives its slot back when it ends);
+        // they are not valid across hipDeviceReset().
         static std::mutex mu;
-        static int* per_device[64] = { nullptr };
+        static std::vector<std::pair<int, int*>> per_device;
         std::lock_guard<std::mutex> lk(mu);
-        const int dv = device_ >= 0 && device_ < 64 ? device_ : 0;
-        if (!per_device[dv]) { HIP_OK(hipMalloc(&per_device[dv], kCuSlots * 4)); HIP_OK(hipMemset(per_device[dv], 0, kCuSlots * 4)); }
-        d_cu_slots_ = per_device[dv];
+        int dv = -1;
+        HIP_OK(hipGetDevice(&dv));
+        int* slots = nullptr;
+        for (const auto& e : per_device) if (e.first == dv) slots = e.second;
+        if (!slots) {
+            HIP_OK(hipMalloc(&slots, kCuSlots * 4));
+            if (hipMemset(slots, 0, kCuSlots * 4) != hipSuccess) { (void)hipFree(slots); err_ = "hipMemset of the per-CU counters failed"; return; }
+            per_device.push_back({ dv, slots });
+        }
+        d_cu_slots_ = slots;
     }
     kname_ = pr_ ? std::string(pr_w1_ ? "ldpc_layered_pr_kernel<w1>" : "ldpc_layered_pr_kernel") : "ldpc_layered_kernel<" + std::to_string(dmax_) + (dense_ ? ", dense>" : std::string(v2_ ? ", packed" : chain_plain_ ? ", chain" : "") + (solo_ ? ", solo>" : hz2_ ? ", hz2>" : soft_bar_ ? ", soft>" : ">"));
     lds_bytes_ = pr_ ? pr_lds_bytes(sched_.N, sched_.K) : 2 * half_lds_bytes(sched_.N);
@@ -422,7 +448,7 @@ void LdpcDecoderHip::launch_sweep(const int8_t* in, bool resume, int stop_on_goo
     la.msgs = d_msgs_ + fb * sched_.q * words_per_check_ * kMsgStride;
     la.iters = d_iters_ + fb; la.good = d_good_ + fb; la.target = resume ? d_target_ + fb : nullptr;
     const bool gs = gsync_on_ && !resume && stop_on_good; // group-synchronous stop: bit 2 of the flag word; its words start from zero
-    if (gs) (void)hipMemsetAsync(d_gsync_ + 2 * (size_t)(frame_base / G_), 0, (size_t)((n_frames + G_ - 1) / G_) * 8, stream); // (frame_base is a multiple of the group size: enqueue())
+    if (gs) (void)hipMemsetAsync(d_gsync_ + frame_base, 0, (size_t)n_frames * 4, stream); // (frame_base is a multiple of the group size: enqueue())
     la.n_frames = n_frames; la.N = sched_.N; la.K = sched_.K; la.q = sched_.q; la.cap = max_trials; la.stop_on_good = stop_on_good | (soft_bar_ ? 2 : 0) | (gs ? 4 : 0);
     la.tdbg = d_tdbg_; la.lds_bytes = solo_ ? half_lds_bytes(sched_.N) : lds_bytes_; la.stream = stream; la.dense = dense_;
     la.v2 = pr_ ? pr_w1_ : v2_; la.solo = solo_; la.chain = chain_plain_; la.hz2 = hz2_; la.soft = soft_bar_; la.cu_slots = d_cu_slots_;

@@ -81,7 +81,7 @@ __host__ __device__ constexpr int rec_stride_wave(int dmax) { return 2 * dmax + 
 // and the group size. Kept out of the kernel's argument list on purpose: arguments stay live in SGPRs for the whole kernel, and the
 // one-frame builds of the degree class 16 answered three more of them with 25 more spilled scalars and 2-3 % (measured); here they are
 // fetched with two scalar loads once per update, by the lane that reports.
-constexpr int kRecHeaderWords = 8; // [0,1] iters base, [2,3] group words base, [4] group size, [5] polls before a waiting member gives up, rest unused
+constexpr int kRecHeaderWords = 8; // [0,1] iters base, [2,3] base of the per-frame status words (group_decide), [4] group size, [5] polls before a waiting member gives up, rest unused
 // per frame: N LLR bytes, then the sign-vector area (syndrome test; scratch of the ordered hazard phases during a sweep:
 // at least kChainScratchWords dwords, which is what short frames get instead of their small sign-vector area), then 8 flag words
 #ifndef DVBS2_CHAIN_MAX_BLOCK
@@ -144,44 +144,41 @@ __device__ __forceinline__ void frame_barrier_lds(volatile lds_i32_t* ctr, int& 
 // Group-synchronous stopping rule. The reference decodes a SIMD batch of G frames in lockstep and stops the whole batch at the
 // first update count at which EVERY lane passes the syndrome test (while (bad(any lane) && --trials >= 0),
 // layered_decoder.hh:153). Frames of one group are dispatched together (consecutive workgroups) and run the same instruction
-// stream, so they can simply agree after every test: per group two words in global memory,
-//   arrive   += 1 per member and test;          lastbad = max(update count + 1) over the members that failed a test.
-// A member that FAILS its test at count `it` knows the group goes on and does not wait. A member that PASSES waits until all
-// `members` have reported for `it` and stops iff nobody failed there -- then every member stops at the same count, which is
-// the reference's result, and no resume pass is needed. Returns 1 = stop (group good), 0 = one more update, 2 = gave up waiting
-// (members not co-resident for milliseconds: never observed; the frame then stops at its own good point like in round 1/2 and
-// the host-side resolution, ldpc_group_targets_kernel + resume launches, finishes the group -- a frame only ever advances past
-// a count at which some member is known to have failed, so it can never overshoot the reference's count).
+// stream, so they can simply agree after every test. Round 5: ONE STATUS WORD PER FRAME in global memory, written only by that frame,
+//   status[f] = (update count of the test + 1) << 1 | passed          (0 = nothing reported yet; zeroed per call)
+// A member reports with ONE relaxed store (fire and forget). A member that FAILS at count `it` knows the group goes on and does not
+// wait. A member that PASSES reads the words of all members of its group (the first wave of the frame: lane m reads member m, one
+// 256-byte access) and decides on them alone:
+//   some member is PAST `it` (it only advances past a count at which a failure is known) or failed AT `it`   -> one more update (0)
+//   every member passed AT `it`                                                                              -> stop (1)
+//   else some member has not reported for `it` yet                                                           -> poll again
+// Every member therefore leaves at the first count at which all pass -- the reference's count -- and no resume pass is needed.
+// Each word has a single writer and its value only grows, so the decision needs no ordering BETWEEN words and no read-modify-write:
+// rounds 3-4 kept {arrive, lastbad} per group, updated by a failing member with two separate relaxed atomics whose order at the L2
+// the memory model does not promise; that dependence is gone. Relaxed at agent scope as before (a release /
+// acquire at agent scope writes back and invalidates the per-XCD L2: 12 % of the never-converging batch, measured in round 3).
+// Returns 2 = gave up waiting after spin_max polls (members not co-resident for milliseconds: never observed; the frame then stops
+// at its own good point like in rounds 1-2 and the host-side resolution, ldpc_group_targets_kernel + resume launches, finishes the
+// group -- a frame only ever advances past a count at which some member is known to have failed, so it can never overshoot).
+// Called by ALL lanes of the frame's first wave (wave-uniform arguments); groups of at most 64 frames.
 constexpr int kGroupSpinMax = 1 << 12; // polls of ~2 us
-// All atomics are RELAXED at agent scope: a release / acquire at agent scope writes back and invalidates the (per-XCD) L2, which
-// at one report per frame and update cost the never-converging batch 12 % (measured). No ordering with other memory is needed --
-// only the two words themselves carry information, both live in one 8-byte slot (one cache line, one coherence point, and a
-// member's two updates are issued in order by one lane), and the reader fetches `lastbad` with an atomic read-modify-write after
-// it has seen the arrival count, so it observes every `lastbad` update of the members it counted.
-// Round 4: the two words are ONE 8-byte slot {arrive (low), lastbad (high)} and a passing member reads both with a single 64-bit atomic --
-// its own arrival is a returning 64-bit add, a poll a 64-bit load: one round trip to the L2 after the last member has arrived instead of
-// three (max, load, max; ~1 us each, 4-5 % of an update at the operating point), and arrive / lastbad are one consistent snapshot (the
-// reader can no longer see an arrival without the failure that member reported before it: both of a failing member's updates go to the
-// same 8 bytes, in order, at one atomic unit).
-__device__ __forceinline__ int group_decide(int* gw /*{arrive, lastbad} of this frame's group, 8-byte aligned*/, int members, int it, bool good, int spin_max = kGroupSpinMax)
+__device__ __forceinline__ int group_decide(int* st /*status words of this frame's group*/, int members, int me /*this frame's index in its group*/,
+                                            int it, bool good, int lane, int spin_max = kGroupSpinMax)
 {
-    if (!good) {
-        __hip_atomic_fetch_max(gw + 1, it + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_fetch_add(gw, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return 0; // (nothing is waited for: both are fire-and-forget)
-    }
-    unsigned long long* gq = reinterpret_cast<unsigned long long*>(gw);
-    unsigned long long v = __hip_atomic_fetch_add(gq, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1ull; // (arrive < 2^32: no carry into lastbad)
-    const int want = members * (it + 1);
+    const int mine = ((it + 1) << 1) | (good ? 1 : 0);
+    // (measured against an atomic max without a returned value -- the same thing for a value that only grows --: identical rates on
+    // short 1/4, 2/5, 1/4 normal, B4 and medium 1/5, where a frame reports every 40-90 us: notes/r05_experiments.md)
+    if (lane == 0) __hip_atomic_store(st + me, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!good) return 0; // (nothing is waited for)
     for (int spin = 0;; spin++) {
-        const int lastbad = (int)(v >> 32), arrive = (int)(uint32_t)v;
-        // a member that already failed at this count settles it without waiting for the rest (the slow frames run ahead: a
-        // failing pre-test skips the full test)
-        if (lastbad > it) return 0;
-        if (arrive >= want) return 1; // everybody has reported for this count and nobody failed
+        int s = mine; // lanes without a member, and this frame itself (its own store need not be visible to its own load yet), are neutral
+        if (lane < members && lane != me) s = __hip_atomic_load(st + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool goes_on = s > mine || s == mine - 1; // a later count, or this count failed
+        const bool missing = s < mine - 1;              // an earlier count (or nothing yet)
+        if (__ballot(goes_on) != 0) return 0;
+        if (__ballot(missing) == 0) return 1;
         if (spin >= spin_max) return 2;
         __builtin_amdgcn_s_sleep(8);
-        v = __hip_atomic_load(gq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -375,6 +372,12 @@ template <int DMAX, bool HZ2> constexpr bool kLowReg = DMAX >= kLowRegMinDmax;
 // and the class 20 what its one table gains -- so: 16 (3/4 normal + 5 % net, short 5/6 + 2 %, short 2/3 - 4 %), 24 (5/6 normal + 1.3 %),
 // 32 (9/10 normal + 8 %).
 template <int DMAX, bool HZ2> constexpr bool kTlc = (DMAX == 16 || DMAX == 24 || DMAX == 32) && !HZ2;
+// Hazard layers with the packed first / last phase (check_node_hazard<..., V2P>, round 5): compiled into the packed builds of the degree
+// classes from DVBS2_V2P_MIN_DMAX up -- the classes whose hazard layers all took the plain node (no packed chain node there).
+#ifndef DVBS2_V2P_MIN_DMAX
+#define DVBS2_V2P_MIN_DMAX 20
+#endif
+__host__ __device__ constexpr bool v2p_class(int dmax) { return dmax >= DVBS2_V2P_MIN_DMAX; }
 __host__ __device__ constexpr bool tlc_class(int dmax) { return dmax == 16 || dmax == 24 || dmax == 32; }
 constexpr int kTlcLowRegMinDmax = 24; // from this degree class on a two-level-chain layer keeps its regular entries in the low-register form
 __device__ __forceinline__ int pm_pack(int magp, int d) { return (int)__builtin_amdgcn_perm((uint32_t)magp, (uint32_t)d, 0x0c0c0400u); } // d.b0 | magp.b0 << 8
@@ -771,7 +774,11 @@ template <int DEG, int NC, bool LAYER0, bool PR = false, bool LAST = false, bool
           bool LR = false /*low-register form (see check_node_lr): regular entries keep one packed word, their addresses are computed twice*/,
           bool TLC = false /*two-level walk with the near pair as a LANE CHAIN (round 3), see below*/,
           bool CHAINOK = true /*false: no lane chain in this build (the 80-VGPR build since round 4, see kLaneChainBuilt)*/,
-          bool CLASS8 = false /*the kernel of the degree class <= 8: early pair reads, walk on absolute addresses (DVBS2_EARLY_PAIR_MAXDEG)*/>
+          bool CLASS8 = false /*the kernel of the degree class <= 8: early pair reads, walk on absolute addresses (DVBS2_EARLY_PAIR_MAXDEG)*/,
+          bool V2P = false /*round 5: FIRST and LAST phase in the packed form of check_node_v2 (pairs of regular entries in the halves of one
+                             register, one-add addresses from this wave's record, two's complement messages in pair-byte order); the ordered
+                             phase in between is untouched. `ent` is then the per-wave record: S0w[DMAXV], lane masks of the first NFIXH slots*/,
+          int DMAXV = 0, bool P6 = false>
 __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, const uint32_t* ent, int jj, int lb, bool work,
                                                   int block, int block2 /*two-level walk: rows per outer block, 0 = off*/, const uint32_t* mw, uint32_t* nm, int own_in, int* carry,
                                                   lds_u32_t* tab /*lane_chain_words(block) of LDS scratch when the layer is a lane chain*/,
@@ -783,13 +790,22 @@ __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, con
     constexpr bool OWN_REG = PR && !LAST;     // entry DEG-2 (see check_node)
     constexpr bool PREV_REG = PR && !LAYER0;  // entry DEG-1
     static_assert(!(LR && PR), "the low-register form is for the classic layout");
+    static_assert(!V2P || (!LAYER0 && !PR && !LR && (NC % 2) == 0 && DEG - NC >= 2), "packed phases: regular layers of the classic layout, ordered entries in pairs");
+    // ---- packed first / last phase (V2P): state of the regular PAIRS between the phases (check_node_v2) ----
+    constexpr int NP = (DEG + 1) / 2;                  // pairs; pairs 0 .. NC/2 - 1 hold the ordered entries
+    constexpr int NPH = NC / 2;
+    constexpr bool ODD = (DEG & 1) != 0;               // the upper half of the last pair is a pad
+    constexpr int NFIXH = V2P ? ((DMAXV / 2) < DEG - 2 ? (DMAXV / 2) : DEG - 2) : 0; // fix slots of the record: the NC ordered entries first, then the mixed regular ones
+    constexpr bool KEEP_AD = !V2P || DEG <= 16;        // high degrees compute the regular entries' addresses again in the last phase
+    v2s16 dP[V2P ? NP : 1], aP[V2P ? NP : 1];
+    uint32_t sxp = 0;
     constexpr int NAD = LR ? NC : DEG; // LR: only the ordered entries keep their addresses
     int ad[NAD], inp[LR ? NC : DEG], mg[LR ? NC : DEG];
     int pm[LR ? DEG : 1];  // LR: regular entry k keeps pm[k] (check_node_lr)
     // Lane-chain layers of the low degree classes: the pair's two LLR bytes are read WITH the regular entries (one LDS round trip for all
     // seven instead of three in a row on the wave that walks the chain afterwards). A value read here is used only by the rows for which
     // no earlier row of this layer writes that bit: entry 0 of the rows below 360 - block, entry 1 of the heads.
-    constexpr bool kEarlyPair = CLASS8 && DEG <= DVBS2_EARLY_PAIR_MAXDEG && NC == 2 && !LR && !PR && CHAINOK && DEG <= DVBS2_FWALK_MAXDEG;
+    constexpr bool kEarlyPair = CLASS8 && DEG <= DVBS2_EARLY_PAIR_MAXDEG && NC == 2 && !LR && !PR && CHAINOK && DEG <= DVBS2_FWALK_MAXDEG && !V2P;
     int Lh01[2] = { 0x80, 0x80 };
     int p0 = 0, p1 = 0;
     const int jjb = jj + lb, jjb360 = jjb - kM;
@@ -801,6 +817,35 @@ __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, con
         return wrap_addr(jj, jjb, jjb360, ent[2 * k], ent[2 * k + 1]);
     };
     __builtin_amdgcn_s_setprio(0); // as in check_node; the ordered steps below run at the top priority
+    auto v2p_addresses = [&](int first) { // one add per entry from this wave's record (+ 360 under the record's lane mask in the fix slots)
+#pragma unroll
+        for (int k = 0; k < DEG; k++) if (k >= first) ad[k] = jjb + (int)ent[k];
+#pragma unroll
+        for (int k = 0; k < NFIXH; k++) if (k >= first) ad[k] = fix_wrap(ad[k], ent[DMAXV + 2 * k], ent[DMAXV + 2 * k + 1]);
+    };
+    if constexpr (V2P) {
+        if (work) {
+            v2p_addresses(0);
+            int Lb[DEG];
+#pragma unroll
+            for (int k = NC; k < DEG; k++) Lb[k] = lds_rd(ad[k]);
+#pragma unroll
+            for (int j = NPH; j < NP; j++) {
+                const uint32_t M = msg_pair16<P6>(mw, j);
+                const uint32_t hi = (ODD && j == NP - 1) ? 0x80u : (uint32_t)Lb[2 * j + 1];
+                const uint32_t L = __builtin_amdgcn_perm(hi, (uint32_t)Lb[2 * j], 0x040c000cu) ^ 0x80008000u;
+                dP[j] = __builtin_elementwise_sub_sat(as_v2s(L), as_v2s(M));
+                sxp ^= as_u32(dP[j]);
+                aP[j] = __builtin_elementwise_max(dP[j], __builtin_elementwise_sub_sat(as_v2s(0u), dP[j]));
+            }
+            int mgr[DEG - NC];
+#pragma unroll
+            for (int k = NC; k < DEG; k++) mgr[k - NC] = (k & 1) ? (int)(as_u32(aP[k >> 1]) >> 16) : (int)(as_u32(aP[k >> 1]) & 0xffffu);
+            two_smallest<DEG - NC>(mgr, p0, p1); // raw |inp| << 8 of the regular entries
+            min0 = (int)(__builtin_elementwise_sub_sat((uint32_t)(p0 & 0x7f00), 256u) >> 8); // R2 on the partial minimum: 0 .. 126 (what the ordered phase takes)
+            signs = (int)(sxp ^ (sxp << 16));                                                  // bit 31: parity of the regular entries' signs (the only bit the ordered phase looks at)
+        }
+    } else
     if constexpr (LR) {
         if (work) {
 #pragma unroll
@@ -842,8 +887,10 @@ __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, con
         min0 = clamp_mag(min0); min1 = clamp_mag(min1);
     }
     DVBS2_PH(0); // P1: regular entries read and reduced
+    if constexpr (!V2P) {
 #pragma unroll
     for (int w = 0; w < (DEG + 3) / 4; w++) nm[w] = 0;
+    }
     // P2 keeps only what the NEXT block needs on its critical path: the new hazard LLRs. For hazard entry k the
     // magnitude sent back is the minimum over all OTHER entries = min(partial min0 of the regular entries, the
     // other hazard magnitudes) and the sign is the xor of all other signs; the merge of the hazard entries into
@@ -851,7 +898,11 @@ __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, con
     if (PR && (DEG + 3) / 4 < 2) nm[1] = 0;
     int hout[NC], hmb[NC];
 #pragma unroll
-    for (int k = 0; k < NC; k++) { hout[k] = 0; inp[k] = 0; mg[k] = 127; hmb[k] = (int)((mw[k >> 2] >> (8 * (k & 3))) & 0xffu); }
+    for (int k = 0; k < NC; k++) {
+        hout[k] = 0; inp[k] = 0; mg[k] = 127;
+        if constexpr (V2P) hmb[k] = (int)(((mw[k >> 2] >> (8 * (((k >> 1) & 1) + 2 * (k & 1)))) & 0xffu) ^ 0x80u); // pair-byte order, two's complement -> offset binary
+        else hmb[k] = (int)((mw[k >> 2] >> (8 * (k & 3))) & 0xffu);
+    }
     // One ordered step per block of `block` rows. A step is a chain of dependent instructions of a single wave (the
     // next block reads what this one wrote), so its length is what a hazard layer costs: rel = jj - start is kept
     // incrementally (one subtract + one unsigned compare select the rows of the block).
@@ -1264,6 +1315,52 @@ __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, con
     }
     if (!lane_chain || !(LR || DEG <= 20)) lds_barrier(); // (uniform; the last phase of a two-barrier lane chain and the outputs below touch different bits)
     DVBS2_PH(6); // ordered steps of the block scheme + closing barrier / completion of the chain rows
+    if constexpr (V2P) {
+        // LAST PHASE, packed: the ordered entries enter the packed domain as pairs [inp << 8] (what they read in their step is final), the
+        // two smallest magnitudes are merged over everything, and every pair's outputs follow as in check_node_v2. The ordered entries'
+        // LLRs were written in their step (a later row may have replaced them since): only their MESSAGES are produced here -- the same
+        // "minimum and sign product over all other entries" the step computed, so the two agree by construction.
+        if (work) {
+            if constexpr (!KEEP_AD) v2p_addresses(NC);
+            int m4[NC + 2];
+            m4[0] = p0; m4[1] = p1;
+#pragma unroll
+            for (int j = 0; j < NPH; j++) {
+                const uint32_t dh = __builtin_amdgcn_perm((uint32_t)inp[2 * j + 1], (uint32_t)inp[2 * j], 0x040c000cu); // [inp_hi << 8 | inp_lo << 8]
+                dP[j] = as_v2s(dh);
+                sxp ^= dh;
+                aP[j] = __builtin_elementwise_max(dP[j], __builtin_elementwise_sub_sat(as_v2s(0u), dP[j]));
+                m4[2 + 2 * j] = (int)(as_u32(aP[j]) & 0xffffu); m4[3 + 2 * j] = (int)(as_u32(aP[j]) >> 16);
+            }
+            int n0, n1;
+            two_smallest<NC + 2>(m4, n0, n1);
+            n0 &= 0x7f00; n1 &= 0x7f00;
+            const int n0m = (int)__builtin_elementwise_sub_sat((uint32_t)n0, 256u), n1m = (int)__builtin_elementwise_sub_sat((uint32_t)n1, 256u);
+            const int B0 = n0, B1 = n0 + n1m - n0m, T = n1m + n0;
+            const v2s16 B0p = { (short)B0, (short)B0 }, B1p = { (short)B1, (short)B1 }, Tp = { (short)T, (short)T };
+            const uint32_t tm = (uint32_t)((int)(sxp ^ (sxp << 16)) >> 31);
+            uint32_t R[NP];
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int j = 0; j < NP; j++) {
+                const v2s16 cl = __builtin_elementwise_min(__builtin_elementwise_max(aP[j], B0p), B1p);
+                const v2s16 other = Tp - cl;
+                const v2s16 sg = as_v2s(as_u32(dP[j]) ^ tm) >> (v2s16){ 15, 15 };
+                const v2s16 out = as_v2s(as_u32(other) ^ as_u32(sg)) - sg;
+                if (j >= NPH) {
+                    const uint32_t nl = (as_u32(__builtin_elementwise_add_sat(dP[j], out)) ^ 0x80008000u) >> 8;
+                    lds_wr(ad[2 * j], (int)nl);
+                    if (!(ODD && j == NP - 1)) lds_wr_hi(ad[2 * j + 1], nl);
+                }
+                R[j] = as_u32(__builtin_elementwise_min(__builtin_elementwise_max(out, (v2s16){ -32 * 256, -32 * 256 }), (v2s16){ 31 * 256, 31 * 256 }));
+            }
+            __builtin_amdgcn_s_setprio(3);
+            if (ODD) R[NP - 1] &= 0x0000ffffu;
+            msg_pack16<P6, NP, DMAXV / 4>(R, nm);
+        }
+        DVBS2_PH(7);
+        return;
+    }
     if constexpr (NC == 2) { mg[0] = clamp_mag(mg[0]); mg[1] = clamp_mag(mg[1]); } // raw in the loop (127 where no step ran: idle rows)
 #pragma unroll
     for (int k = 0; k < NC; k++) {
@@ -1358,6 +1455,21 @@ __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, con
         else DVBS2_HAZ_CALL1(D, NCV, (kLowReg<DMAX, HZ2>), false) } }
 #define DVBS2_HAZ_CASE(D) case D: if constexpr (D >= 4 && D <= DMAX && D > DMAX - 8) { \
         if (nc == 2) DVBS2_HAZ_CALL((D >= 4 ? D : 4), 2) else if (nc == 4) DVBS2_HAZ_CALL((D >= 4 ? D : 4), 4) else { if constexpr (HZ2 && DMAX <= kMaxHazard12Dmax) { if (nc == 8) DVBS2_HAZ_CALL((D >= 4 ? D : 4), 8) else DVBS2_HAZ_CALL((D >= 4 ? D : 4), 12) } else DVBS2_HAZ_CALL((D >= 4 ? D : 4), 8) } } break;
+// The same with the packed first / last phase (check_node_hazard<..., V2P>): regular layers i > 0 of the builds with packed nodes whose
+// wave record the host laid out in the packed format (header bit 14); the ordered phase is the plain one, instantiation for instantiation.
+#define DVBS2_HAZP_CALL1(D, NCV, TLCV) { check_node_hazard<D, NCV, false, false, false, HZ2, false, TLCV, (MINW == 1), (DMAX <= 8), true, DMAX, P6>(lds_all, ent, jj, lb, work, block, block2, mw, nm, 0, nullptr, htab, hb_ctr, hb_epoch, hb_lane, hz_ph); }
+#define DVBS2_HAZP_CALL(D, NCV) { if constexpr (D - 2 >= NCV) { \
+        if constexpr (kTlc<DMAX, HZ2> && (!SOFT || DVBS2_TLC_SOFT) && MINW == 1 && (NCV == 4 || NCV == 8)) { if (block2 > 0 && htab != nullptr) DVBS2_HAZP_CALL1(D, NCV, true) else DVBS2_HAZP_CALL1(D, NCV, false) } \
+        else DVBS2_HAZP_CALL1(D, NCV, false) } }
+#define DVBS2_HAZP_CASE(D) case D: if constexpr (D >= 4 && D <= DMAX && D > DMAX - 8) { \
+        if (nc == 2) DVBS2_HAZP_CALL((D >= 4 ? D : 4), 2) else if (nc == 4) DVBS2_HAZP_CALL((D >= 4 ? D : 4), 4) else DVBS2_HAZP_CALL((D >= 4 ? D : 4), 8) } break;
+#define DVBS2_HAZP_SWITCH switch (deg) { \
+        DVBS2_HAZP_CASE(4) DVBS2_HAZP_CASE(5) DVBS2_HAZP_CASE(6) DVBS2_HAZP_CASE(7) DVBS2_HAZP_CASE(8) \
+        DVBS2_HAZP_CASE(9) DVBS2_HAZP_CASE(10) DVBS2_HAZP_CASE(11) DVBS2_HAZP_CASE(12) DVBS2_HAZP_CASE(13) DVBS2_HAZP_CASE(14) \
+        DVBS2_HAZP_CASE(15) DVBS2_HAZP_CASE(16) DVBS2_HAZP_CASE(17) DVBS2_HAZP_CASE(18) DVBS2_HAZP_CASE(19) DVBS2_HAZP_CASE(20) \
+        DVBS2_HAZP_CASE(21) DVBS2_HAZP_CASE(22) DVBS2_HAZP_CASE(23) DVBS2_HAZP_CASE(24) DVBS2_HAZP_CASE(25) DVBS2_HAZP_CASE(26) \
+        DVBS2_HAZP_CASE(27) DVBS2_HAZP_CASE(28) DVBS2_HAZP_CASE(29) DVBS2_HAZP_CASE(30) DVBS2_HAZP_CASE(31) DVBS2_HAZP_CASE(32) \
+        default: break; }
 #define DVBS2_HAZ_SWITCH switch (deg) { \
         DVBS2_HAZ_CASE(4) DVBS2_HAZ_CASE(5) DVBS2_HAZ_CASE(6) DVBS2_HAZ_CASE(7) DVBS2_HAZ_CASE(8) \
         DVBS2_HAZ_CASE(9) DVBS2_HAZ_CASE(10) DVBS2_HAZ_CASE(11) DVBS2_HAZ_CASE(12) DVBS2_HAZ_CASE(13) DVBS2_HAZ_CASE(14) \
@@ -1591,7 +1703,11 @@ __global__ __launch_bounds__(SOLO ? kSoloThreads : kThreads, SOLO ? 4 : MINW) vo
                 if (nf >= DVBS2_P6_DW) dst[w] = MSG_LD(soff, w, r4);
                 else if (nf >= 1) dst[w] = (uint32_t)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(mrs, r4 >> 1, soff + w * (kMsgStride * 4), 1 /* sc0: a sub-dword store does not update a line held in the vector L1 */);
                 else dst[w] = 0u;
-            } else dst[w] = MSG_LD(soff, w, r4);
+            }
+#ifdef DVBS2_EXP_ONEWORD // timing-only bound (wrong results): half of a check's message words move, the rest is derived
+            else if (w >= (MW + 1) / 2) dst[w] = 0u; // (derived from the loaded half where the words are consumed: DVBS2_ONEWORD_FILL)
+#endif
+            else dst[w] = MSG_LD(soff, w, r4);
         }
     };
     auto msg_store = [&](const uint32_t* src, int soff, int r4, bool packed, int dg) {
@@ -1601,9 +1717,18 @@ __global__ __launch_bounds__(SOLO ? kSoloThreads : kThreads, SOLO ? 4 : MINW) vo
                 const int nf = dg - 5 * w;
                 if (nf >= DVBS2_P6_DW) MSG_ST(src[w], soff, w, r4);
                 else if (nf >= 1) __builtin_amdgcn_raw_buffer_store_b16((unsigned short)src[w], mrs, r4 >> 1, soff + w * (kMsgStride * 4), 0);
-            } else MSG_ST(src[w], soff, w, r4);
+            }
+#ifdef DVBS2_EXP_ONEWORD
+            else if (w >= (MW + 1) / 2) { asm volatile("" :: "v"(src[w])); }
+#endif
+            else MSG_ST(src[w], soff, w, r4);
         }
     };
+#ifdef DVBS2_EXP_ONEWORD // (the words that were not loaded: a function of the loaded ones, computed where a layer consumes its messages)
+#define DVBS2_ONEWORD_FILL(p, w) ((w) >= (MW + 1) / 2 ? ((p)[(w) - (MW + 1) / 2] ^ 0x01030107u) : (p)[w])
+#else
+#define DVBS2_ONEWORD_FILL(p, w) ((p)[w])
+#endif
     // bnl = 0 before the first update (layered_decoder.hh:27-31,149): a frame's first sweep (it == 0, in the first pass or
     // when a frame that stopped at once is resumed) takes offset-binary zero bytes instead of loading them -- no memset
     // of the record area, no read traffic in sweep 0
@@ -1696,17 +1821,17 @@ __global__ __launch_bounds__(SOLO ? kSoloThreads : kThreads, SOLO ? 4 : MINW) vo
         const bool gs = (stop_on_good & 5) == 5; // group-synchronous stop (group_decide), first pass only
         if (!finished && (it >= tgt || (!gs && (stop_on_good & 1) && is_good))) finished = true;
         lds_barrier(); // everyone has read flags[0]
-        if (tid == 0) {
+        if (wave_u == 0) { // (the whole first wave: group_decide reads one status word per lane)
             int fin = finished ? 1 : 0;
             if (gs && !finished) {
                 const uint32_t* hd = recs - kRecHeaderWords; // (uniform: scalar loads)
                 const int* iters0 = reinterpret_cast<const int*>(((unsigned long long)hd[1] << 32) | hd[0]);
-                int* gwords = reinterpret_cast<int*>(((unsigned long long)hd[3] << 32) | hd[2]);
+                int* status = reinterpret_cast<int*>(((unsigned long long)hd[3] << 32) | hd[2]);
                 const int G = (int)hd[4];
                 const int g = f / G; // within this launch (its first frame is a multiple of the group size)
-                fin = group_decide(gwords + 2 * ((int)(iters - iters0) / G + g), min(G, n_frames - g * G), it, is_good, (int)hd[5]) != 0;
+                fin = group_decide(status + (iters - iters0) + g * G, min(G, n_frames - g * G), f - g * G, it, is_good, lane, (int)hd[5]) != 0;
             }
-            flags[0] = 0; flags[2] = 0; flags[1] = fin;
+            if (tid == 0) { flags[0] = 0; flags[2] = 0; flags[1] = fin; }
         }
         lds_only_barrier();
         if (gs) finished = flags[1] != 0; // (uniform over the frame)
@@ -1726,7 +1851,12 @@ __global__ __launch_bounds__(SOLO ? kSoloThreads : kThreads, SOLO ? 4 : MINW) vo
         constexpr bool kWaitStore = (DVBS2_WAIT_BEFORE_STORE != 0) && !SOFT;
         if (work) {
 #pragma unroll
-            for (int w = 0; w < MW; w++) pre[w] = zero_msgs ? 0x80808080u : MSG_LD(0, w, row4);
+            for (int w = 0; w < MW; w++) {
+#ifdef DVBS2_EXP_ONEWORD
+                if (w >= (MW + 1) / 2) { pre[w] = 0u; continue; }
+#endif
+                pre[w] = zero_msgs ? 0x80808080u : MSG_LD(0, w, row4);
+            }
         }
         // Layer records are double-buffered in SGPRs: the scalar loads of layer i+1 are issued at the top of layer i
         // (an un-prefetched s_load at the head of every layer was a quarter of the sweep time). Small records are
@@ -1792,7 +1922,7 @@ __global__ __launch_bounds__(SOLO ? kSoloThreads : kThreads, SOLO ? 4 : MINW) vo
                     // v2: this wave's record is in the packed node's format (two's complement messages)
                     uint32_t mw[MW], nm[MW];
 #pragma unroll
-                    for (int w = 0; w < MW; w++) mw[w] = zero_msgs ? (v2 ? 0u : 0x80808080u) : pre[w];
+                    for (int w = 0; w < MW; w++) mw[w] = zero_msgs ? (v2 ? 0u : 0x80808080u) : DVBS2_ONEWORD_FILL(pre, w);
                     if (i + 1 < q && !zero_msgs) msg_load(pre, mso + kLayerBytes, row4, npacked, ndeg);
                     if constexpr (V2) { if (v2) { DVBS2_V2_SWITCH } else DVBS2_DEG_SWITCH } else DVBS2_DEG_SWITCH
                     DVBS2_WAIT_VM0();
@@ -1820,14 +1950,19 @@ __global__ __launch_bounds__(SOLO ? kSoloThreads : kThreads, SOLO ? 4 : MINW) vo
                     }
                     uint32_t mw[MW], nm[MW];
 #pragma unroll
-                    for (int w = 0; w < MW; w++) mw[w] = (work && !zero_msgs) ? pre[w] : (hv2 ? 0u : 0x80808080u);
+                    for (int w = 0; w < MW; w++) mw[w] = (work && !zero_msgs) ? DVBS2_ONEWORD_FILL(pre, w) : (hv2 ? 0u : 0x80808080u);
                     if (work && i + 1 < q && !zero_msgs) msg_load(pre, mso + kLayerBytes, row4, npacked, ndeg);
+                    // hvp: the generic hazard node with the packed first / last phase (header bit 14 of this wave's record; every wave of the
+                    // layer runs the same ordered phase, whichever form its own record has)
+                    const bool hvp = V2 && v2p_class(DMAX) && ((hdr >> 14) & 1u);
                     if constexpr ((V2 || CHAIN) && DMAX <= 16) { // (the chain node's register state costs the high-degree builds more than it saves: not built there)
-                        if (hv2) {
+                        if (hv2 && !hvp) {
                             lds_u32_t* htab16 = lds_align16<lds_u32_t>(sv); // 16-byte records
                             DVBS2_CHAIN_SWITCH
-                        } else DVBS2_HAZ_SWITCH
-                    } else DVBS2_HAZ_SWITCH
+                        } else if constexpr (V2 && v2p_class(DMAX)) { if (hvp) { DVBS2_HAZP_SWITCH } else DVBS2_HAZ_SWITCH }
+                        else DVBS2_HAZ_SWITCH
+                    } else if constexpr (V2 && v2p_class(DMAX)) { if (hvp) { DVBS2_HAZP_SWITCH } else DVBS2_HAZ_SWITCH }
+                    else DVBS2_HAZ_SWITCH
                     DVBS2_WAIT_VM0(); // (on every path, so that nothing is pending behind it whatever the branch)
                     if (work) msg_store(nm, mso, row4, hv2, deg);
                 } else {

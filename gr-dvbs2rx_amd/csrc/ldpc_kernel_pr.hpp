@@ -282,17 +282,17 @@ __global__ __launch_bounds__(kThreads, 6) void ldpc_layered_pr_kernel(
         const bool gs = (stop_on_good & 5) == 5;
         if (!finished && (it >= tgt || (!gs && (stop_on_good & 1) && is_good))) finished = true;
         __syncthreads();
-        if (tid == 0) {
+        if (tid < 64) { // the frame's first wave (group_decide reads one status word per lane)
             int fin = finished ? 1 : 0;
             if (gs && !finished) {
                 const uint32_t* hd = recs - kRecHeaderWords;
                 const int* iters0 = reinterpret_cast<const int*>(((unsigned long long)hd[1] << 32) | hd[0]);
-                int* gwords = reinterpret_cast<int*>(((unsigned long long)hd[3] << 32) | hd[2]);
+                int* status = reinterpret_cast<int*>(((unsigned long long)hd[3] << 32) | hd[2]);
                 const int G = (int)hd[4];
                 const int g = f / G;
-                fin = group_decide(gwords + 2 * ((int)(iters - iters0) / G + g), min(G, n_frames - g * G), it, is_good, (int)hd[5]) != 0;
+                fin = group_decide(status + (iters - iters0) + g * G, min(G, n_frames - g * G), f - g * G, it, is_good, tid, (int)hd[5]) != 0;
             }
-            flags[0] = 0; flags[2] = 0; flags[1] = fin;
+            if (tid == 0) { flags[0] = 0; flags[2] = 0; flags[1] = fin; }
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); // LDS only: the group report above is not waited for (ldpc_kernel.hpp, frame_barrier_lds)
         if (gs) finished = flags[1] != 0;

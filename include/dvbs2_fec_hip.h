@@ -57,9 +57,13 @@ int dvbs2_device_count(void);
  * to lie inside ONE registration / allocation visible to the handle's device (a range that spans two registrations with a pageable
  * hole, or any range the runtime cannot vouch for, goes through the handle's pinned buffers: slower, never wrong).
  * Device pointers handed to the *_device entry points: d_llr_in and d_llr_out are accessed with 8-byte loads / stores (align them
- * to 8 bytes: hipMalloc'ed buffers and whole-frame offsets into them are, N is a multiple of 8). */
+ * to 8 bytes: hipMalloc'ed buffers and whole-frame offsets into them are, N is a multiple of 8); a misaligned one is refused with
+ * DVBS2_EINVAL. */
 int dvbs2_host_register(void* p, size_t bytes);
 int dvbs2_host_unregister(void* p);
+/* 1 when [p, p + bytes) lies inside ONE page-locked allocation / registration as the runtime records it (the test the host-buffer
+ * entry applies to the caller's buffers before it lets the copy engine address them directly), else 0. Diagnostics and tests. */
+int dvbs2_host_is_page_locked(const void* p, size_t bytes);
 
 /* ---- parameter map: replaces get_fec_info(), reference lib/fec_params.h:36-39 / fec_params.cc:16-344,
  * plus the table selection of lib/ldpc_decoder_bb_impl.cc:104-307 ---- */

@@ -4,10 +4,12 @@ bit for bit against the reference on the GPU (tests/test_ldpc_gpu.py).
 
 Reference rule (lib/ldpc_decoder/layered_decoder.hh:153): a batch of G frames runs `while (bad(any lane) && --trials >= 0) update`,
 i.e. all frames stop at T = the first update count at which EVERY frame passes its test (or at the cap).
-Protocol: after the test at count `it` a frame reports to its group {arrive += 1; if it failed: lastbad = max(lastbad, it + 1)}.
-A frame that failed continues at once. A frame that passed continues as soon as lastbad > it, stops when all members have arrived
-and lastbad <= it, and may GIVE UP waiting (stop at `it`, to be resumed by the host-side resolution: bring every frame to the largest
-count reached, test there, advance the whole group by one while some frame fails)."""
+Protocol (round 5): ONE status word per frame, written only by that frame: after the test at count `it` it stores
+(it + 1) << 1 | passed. A frame that failed continues at once. A frame that passed looks at the words of the other members: it continues
+as soon as some member is past `it` or failed at `it`, stops when every member passed at `it`, polls again otherwise, and may GIVE UP
+waiting (stop at `it`, to be resumed by the host-side resolution: bring every frame to the largest count reached, test there, advance
+the whole group by one while some frame fails). A poll sees every word at SOME moment between the previous poll and now, independently
+per word (no ordering between words is assumed: single writer, monotone values)."""
 import random
 
 
@@ -25,7 +27,8 @@ def reference_T(patterns, cap):
 
 def simulate(patterns, cap, rng, give_up_prob):
     n = len(patterns)
-    arrive, lastbad = 0, 0
+    hist = [[0] for _ in range(n)]                 # every value a member's status word ever held
+    seen = [[0] * n for _ in range(n)]             # seen[f][m]: index into hist[m] of the newest value f has observed
     it = [0] * n            # update count of each member
     state = ["test"] * n    # test -> (wait | run) -> ... -> stopped
     stopped_at = [None] * n
@@ -36,18 +39,22 @@ def simulate(patterns, cap, rng, give_up_prob):
             if it[f] >= cap:                       # the cap: no report needed, everybody gets here at the same count
                 state[f] = "stopped"; stopped_at[f] = it[f]; continue
             ok = good_at(patterns[f], it[f], cap)
-            if not ok:
-                lastbad = max(lastbad, it[f] + 1)
-            arrive += 1
+            hist[f].append(((it[f] + 1) << 1) | (1 if ok else 0))
             state[f] = "run" if not ok else "wait"
         elif state[f] == "wait":
-            if lastbad > it[f]:
+            mine = ((it[f] + 1) << 1) | 1
+            goes_on = missing = False
+            for m in range(n):
+                if m == f:
+                    continue
+                seen[f][m] = rng.randint(seen[f][m], len(hist[m]) - 1)   # any value between the last one seen and the newest
+                sv = hist[m][seen[f][m]]
+                goes_on |= sv > mine or sv == mine - 1
+                missing |= sv < mine - 1
+            if goes_on:
                 state[f] = "run"
-            elif arrive >= n * (it[f] + 1):
-                if lastbad <= it[f]:
-                    state[f] = "stopped"; stopped_at[f] = it[f]
-                else:
-                    state[f] = "run"
+            elif not missing:
+                state[f] = "stopped"; stopped_at[f] = it[f]
             elif rng.random() < give_up_prob:
                 state[f] = "stopped"; stopped_at[f] = it[f]; gave_up = True
         else:  # run one update

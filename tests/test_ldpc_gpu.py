@@ -69,6 +69,7 @@ VARIANTS = {  # every build of the sweep kernel gives the same bits (environment
     "packed-pair": {"DVBS2_PR": "0", "DVBS2_DENSE": "0", "DVBS2_HZ2": "0", "DVBS2_V2": "1", "DVBS2_SOLO": "0"},    # packed nodes, six-bit messages, pair workgroups
     "plain-solo": {"DVBS2_PR": "0", "DVBS2_DENSE": "0", "DVBS2_HZ2": "0", "DVBS2_V2": "0", "DVBS2_SOLO": "1"},     # scalar nodes, one frame per workgroup
     "packed-solo": {"DVBS2_PR": "0", "DVBS2_DENSE": "0", "DVBS2_HZ2": "0", "DVBS2_V2": "1", "DVBS2_SOLO": "1"},
+    "packed-pair-plain-hazard": {"DVBS2_PR": "0", "DVBS2_DENSE": "0", "DVBS2_HZ2": "0", "DVBS2_V2": "1", "DVBS2_SOLO": "0", "DVBS2_V2P": "0"},  # hazard layers through the plain node (what a wave whose record does not fit the packed format runs)
     "heavy-hazard": {"DVBS2_PR": "0", "DVBS2_DENSE": "0", "DVBS2_HZ2": "1"},                       # twelve ordered entries, two-level walk (degree classes >= 12)
     "soft-barrier": {"DVBS2_PR": "0", "DVBS2_DENSE": "0", "DVBS2_HZ2": "0", "DVBS2_V2": "1", "DVBS2_SOLO": "0", "DVBS2_SOFT_BARRIER": "1"},  # per-frame software barriers
 }
@@ -602,3 +603,89 @@ def test_host_link_measurement_entry():
     for kind, streams in ((0, 1), (0, 4), (1, 1), (2, 1)):
         capi.check(capi.lib.dvbs2_measure_host_copy(0, 64 << 20, streams, kind, h2d, d2h))
         assert 0.2 < h2d.value < 200.0 and 0.2 < d2h.value < 200.0, (kind, streams, h2d.value, d2h.value)
+
+
+def test_host_range_page_locked_predicate():
+    """the host entry lets the copy engine address a caller's buffer directly only when the WHOLE range lies inside one
+    page-locked allocation / registration as the runtime records it (dvbs2_host_is_page_locked = the predicate dvbs2_ldpc_decode
+    applies). Pageable memory, a range that runs past its registration, and a range spanning TWO registrations with a pageable hole
+    between them must all be refused (they go through the handle's pinned buffers instead)."""
+    import ctypes as C
+    import mmap
+    import torch
+    page = mmap.PAGESIZE
+    buf = mmap.mmap(-1, 64 * page)
+    base = C.addressof(C.c_char.from_buffer(buf))
+    assert capi.lib.dvbs2_host_is_page_locked(base, 4 * page) == 0                      # pageable
+    capi.check(capi.lib.dvbs2_host_register(base, 8 * page))                            # pages 0..7
+    capi.check(capi.lib.dvbs2_host_register(base + 9 * page, 8 * page))                 # pages 9..16 (page 8 stays pageable)
+    try:
+        assert capi.lib.dvbs2_host_is_page_locked(base, 8 * page) == 1
+        assert capi.lib.dvbs2_host_is_page_locked(base + page, 3 * page + 17) == 1      # inside, unaligned
+        assert capi.lib.dvbs2_host_is_page_locked(base + 9 * page, 8 * page) == 1
+        assert capi.lib.dvbs2_host_is_page_locked(base, 8 * page + 1) == 0              # runs past the registration
+        assert capi.lib.dvbs2_host_is_page_locked(base + 4 * page, 10 * page) == 0      # spans the hole: both ends are page-locked
+        assert capi.lib.dvbs2_host_is_page_locked(base + 8 * page, page) == 0           # the hole itself
+    finally:
+        capi.check(capi.lib.dvbs2_host_unregister(base))
+        capi.check(capi.lib.dvbs2_host_unregister(base + 9 * page))
+    assert capi.lib.dvbs2_host_is_page_locked(base, 8 * page) == 0
+    t = torch.empty(1 << 20, dtype=torch.uint8).pin_memory()                            # hipHostMalloc'ed by the runtime
+    assert capi.lib.dvbs2_host_is_page_locked(t.data_ptr(), t.numel()) == 1
+    assert capi.lib.dvbs2_host_is_page_locked(t.data_ptr() + 5, t.numel() - 5) == 1
+    assert capi.lib.dvbs2_host_is_page_locked(0, 16) == 0 and capi.lib.dvbs2_host_is_page_locked(base, 0) == 0
+    del t
+
+
+def test_host_entry_large_odd_group_with_registered_buffers():
+    """page-locked caller buffers + a call of more than 1024 frames + a group size whose chunk unit (2 G for odd G) exceeds
+    the first chunk of 512 frames: the chunk plan must stay inside the call (it used to place its first boundary at `unit` > n_frames
+    and copy past the caller's buffers). G = 513 > 64: host-driven group resolution. Against the device entry and, for the first group,
+    the scalar restatement."""
+    import torch
+    table, G, cap = "S2_TABLE_C1", 513, 4
+    nf = 1026
+    N, K, _, _ = T.ldpc_info(table)
+    llr, _ = T.llr_codeword_awgn(table, nf, 91, amp=5, sigma=5.0)
+    llr[5] = T.llr_noise(1, N, 3)[0]
+    guard = 4096                                           # canaries behind every caller buffer
+    xin = np.full(llr.size + guard, 0x55, np.int8); xin[:llr.size] = llr.ravel()
+    bits = np.full(nf * (K // 8) + guard, 0xA5, np.uint8)
+    ret = np.full(2 + guard // 4, 0x7A7A7A7A, np.int32)
+    for a in (xin, bits, ret):
+        capi.check(capi.lib.dvbs2_host_register(a.ctypes.data, a.nbytes))
+    dec = LdpcDecoder(table=table, message_bits=K, group_size=G, max_frames=2 * nf, max_trials=cap, outputmode=capi.OM_MESSAGE)
+    try:
+        capi.check(capi.lib.dvbs2_ldpc_decode(dec._h, xin.ctypes.data, nf, cap, capi.OM_MESSAGE, bits.ctypes.data, None, ret.ctypes.data))
+    finally:
+        for a in (xin, bits, ret):
+            capi.check(capi.lib.dvbs2_host_unregister(a.ctypes.data))
+    assert (bits[nf * (K // 8):] == 0xA5).all() and (ret[2:] == 0x7A7A7A7A).all() and (xin[llr.size:] == 0x55).all()
+    d_in = torch.from_numpy(llr).cuda()
+    d_bits = torch.empty((nf, K // 8), dtype=torch.uint8, device="cuda")
+    d_ret = torch.empty(2, dtype=torch.int32, device="cuda")
+    dec.work_device(d_in.data_ptr(), nf, d_bits.data_ptr(), 0, d_ret.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    assert np.array_equal(bits[:nf * (K // 8)].reshape(nf, K // 8), d_bits.cpu().numpy()) and ret[:2].tolist() == d_ret.cpu().tolist()
+    want, wret = T.oracle_ldpc_decode(table, llr[:G], G, cap)
+    assert ret[0] == wret[0] and np.array_equal(bits[:G * (K // 8)].reshape(G, K // 8), T.pack_bits(want, K))
+    dec.close()
+
+
+def test_misaligned_device_pointers_are_refused():
+    """include/dvbs2_fec_hip.h: d_llr_in / d_llr_out of the *_device entry points are moved with 8-byte loads and stores; a misaligned
+    pointer is DVBS2_EINVAL, not a GPU memory fault."""
+    import torch
+    table = "S2_TABLE_C1"
+    N, K, _, _ = T.ldpc_info(table)
+    dec = LdpcDecoder(table=table, message_bits=K, group_size=32, max_frames=32, max_trials=5, outputmode=capi.OM_MESSAGE)
+    d_in = torch.zeros(32 * N + 16, dtype=torch.int8, device="cuda")
+    d_out = torch.zeros(32 * N + 16, dtype=torch.int8, device="cuda")
+    d_bits = torch.zeros((32, K // 8), dtype=torch.uint8, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    f = capi.lib.dvbs2_ldpc_decode_device
+    assert f(dec._h, d_in.data_ptr() + 4, 32, 5, capi.OM_MESSAGE, d_bits.data_ptr(), None, None, st) == capi.EINVAL
+    assert f(dec._h, d_in.data_ptr(), 32, 5, capi.OM_MESSAGE, d_bits.data_ptr(), d_out.data_ptr() + 1, None, st) == capi.EINVAL
+    assert capi.lib.dvbs2_ldpc_enqueue_device(dec._h, d_in.data_ptr() + 2, 32, 5, capi.OM_MESSAGE, d_bits.data_ptr(), None, None, st) == capi.EINVAL
+    capi.check(f(dec._h, d_in.data_ptr() + 8, 32, 5, capi.OM_MESSAGE, d_bits.data_ptr(), d_out.data_ptr() + 8, None, st))  # 8-byte offsets are fine
+    torch.cuda.synchronize()
+    dec.close()

@@ -87,3 +87,38 @@ def test_eight_ranks_gloo_config5_shares():
     for r, (rank, a, b, dt, frames) in enumerate(res):
         assert (rank, a, b) == (r, 4096 * r, 4096 * (r + 1))
         assert abs(dt - 0.57) < 1e-9 and frames == 32768.0
+
+
+@pytest.mark.gpu
+def test_bench_n2_branch_runs_on_one_gpu():
+    """the N > 1 branch of bench.py executed once before a driver points an 8-GPU node at it -- two ranks under
+    torch.distributed.run exactly as the driver launches them (rendezvous on 127.0.0.1), process group on gloo so that both ranks may
+    share this box's one GPU (DVBS2_DIST_BACKEND; RCCL refuses two ranks on one device). Checks the line the driver parses: n_gpus,
+    the whole-job value, per_rank (gathered over the ranks), config 5 on every rank, and the host feed of every rank."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, DVBS2_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--gate", "first",
+           "--frames", "1024"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.split("\n") if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]  # rank 0 prints ONE line
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak" and d["unit"] == "frames/s"
+    assert d["config"]["frames_per_gpu"] == 1024 and "bit-exact" in d["parity"]
+    pr = d["per_rank"]
+    assert len(pr["frames_per_s"]) == 2 and all(v > 0 for v in pr["frames_per_s"])
+    # whole-job value = frames of both ranks / the slowest rank's time: between one and two times the slower rank's own rate
+    assert 0.9 * pr["min"] <= d["value"] <= 2.0 * pr["max"] * 1.05
+    c5 = d["configs"]["config5"]
+    assert c5["frames_total"] == 2 * c5["frames_per_gpu"] and c5["value"] > 0 and c5["roofline"]["kernel"].startswith("ldpc_layered_kernel<32")
+    host = d["configs"]["config2_host"]["ranks"]
+    for mode in ("pageable", "registered"):
+        assert len(host[mode]["per_rank_frames_per_s"]) == 2 and all(v > 0 for v in host[mode]["per_rank_frames_per_s"])
+    assert d["fallback_rounds"] == 0

@@ -6,7 +6,9 @@ HBM bytes per launch of every BASELINE configuration's dominant kernel from the 
 WRITE_SIZE in separate passes). Per kernel the counters are sums over all its dispatches in the run = a known number of frames
 (warm-up + timed steps, no parity-gate launches); scaled to one launch of the configuration's batch. The file records the digest of
 gr-dvbs2rx_amd/csrc it was profiled at (bench.csrc_sha256); bench.py reports `traffic` only for exactly that tree. Units KiB; FETCH_SIZE doubled (MI355X_MICROARCH.md: gfx950 tallies 128-byte read requests at
-64 B; calibrated in round 1 against this kernel family's known message byte count)."""
+64 B; calibrated in round 1 against this kernel family's known message byte count). Each entry also carries the SQ pass of the same run
+(`sq`: instruction / activity / wait counters summed over the kernel's dispatches + their total duration), from which bench.py computes
+`roofline.limiter`."""
 import json, os, re, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -43,7 +45,7 @@ def counters(section):
     return out
 
 
-fetch, write = counters("pmc_fetch"), counters("pmc_write")
+fetch, write, sqp = counters("pmc_fetch"), counters("pmc_write"), counters("pmc_sq")
 steps, warm = bench["steps"], bench["warmup"]
 G = bench["config"]["group_size"]
 runs = {"config2": (bench["roofline"]["kernel"], bench["config"]["frames_per_gpu"], bench["config"]["max_trials"],
@@ -60,5 +62,8 @@ for name, (kern, frames, trials, total) in runs.items():
     per_launch = (2 * fs + ws) * 1024 * frames // total
     entries.append({"config": name, "kernel": kern, "frames_per_launch": frames, "max_trials": trials, "fetch_size_kb_raw_sum": fs,
                     "write_size_kb_sum": ws, "frames_in_sum": total, "hbm_bytes_per_launch": per_launch, "source": "profiles/" + os.path.basename(src)})
+    if kern in sqp:  # the SQ pass of the same run (sums over its dispatches): bench.py derives `roofline.limiter` from it
+        q = sqp[kern]
+        entries[-1]["sq"] = {"dispatches": q["_dispatches"], "dur_ns": q["_dur_ns"], **{k: v for k, v in q.items() if k.startswith("SQ_")}}
     print(f"{name:12s} {kern:40s} {per_launch/1e9:8.2f} GB per launch of {frames} frames")
 json.dump({"note": __doc__.split("\n\n", 1)[1], "csrc_sha256": csrc_sha256(), "entries": entries}, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
