@@ -174,6 +174,9 @@ LdpcDecoderHip::LdpcDecoderHip(const LdpcTableDesc* table, int out_bits_message,
     soft_bar_ = !pr_ && !dense_ && !solo_ && dmax_ >= 20 && pol_soft;
     if (const char* e = getenv("DVBS2_SOFT_BARRIER")) soft_bar_ = !pr_ && !dense_ && !solo_ && dmax_ >= 20 && atoi(e) != 0; // (built for the degree classes >= 20)
     if (hz2_ || timing_on) soft_bar_ = false;
+    // (the packed build is the table's policy or forced; a later check may still send the table to the plain build, which ignores a chain bit it has no code for)
+    bool packed_intent = !pr_ && !dense_ && !hz2_ && pol_packed;
+    if (const char* e = getenv("DVBS2_V2")) packed_intent = !pr_ && !dense_ && !hz2_ && atoi(e) != 0;
     std::vector<std::vector<int>> layer_order(sched_.q); // record order of every layer's entries (ordered entries first, host-oriented pairs)
     std::vector<int> layer_nc(sched_.q, 0);              // ordered entries the kernel handles in the layer's ordered phase (2, 4, 8, 12; kHazardWalk)
     for (int i = 0; i < sched_.q; i++) {
@@ -190,7 +193,7 @@ LdpcDecoderHip::LdpcDecoderHip(const LdpcTableDesc* table, int out_bits_message,
         int order[64];
         for (int k = 0; k < L.cnt + 2; k++) order[k] = k;
         uint32_t chain = 0;
-        if (!dense_here && L.block <= lane_chain_max && nc_code == 2 && L.n_conflict == 2 && (L.cnt + 2 <= kLaneChainMaxDeg || dmax_ >= kLowRegMinDmax) &&
+        if (!dense_here && L.block <= lane_chain_max && nc_code == 2 && L.n_conflict == 2 && (L.cnt + 2 <= kLaneChainMaxDeg || dmax_ >= kLowRegMinDmax || (packed_intent && v2p_class(dmax_) && L.cnt + 2 <= kLaneChainMaxDegV2p)) &&
             (sched_.N / 360) * kSvWords >= lane_chain_words(L.block)) {
             const LdpcEntry& a = sched_.entries[L.entry_off], & b = sched_.entries[L.entry_off + 1];
             if (a.base == b.base) {
@@ -279,14 +282,32 @@ LdpcDecoderHip::LdpcDecoderHip(const LdpcTableDesc* table, int out_bits_message,
     // with more mixed entries than fix slots, layer 0 and hazard layers keep the classic record (replicated).
     bool v2 = !pr_ && !dense_ && !hz2_ && pol_packed; // (the 80-VGPR build has no packed nodes)
     if (const char* e = getenv("DVBS2_V2")) v2 = !pr_ && !dense_ && !hz2_ && atoi(e) != 0;
+    bool v2p_on = true; // hazard layers with the packed first / last phase (classes from DVBS2_V2P_MIN_DMAX up); DVBS2_V2P=0: experiments, tests
+    if (const char* e = getenv("DVBS2_V2P")) v2p_on = atoi(e) != 0;
+    // "Pure" packed builds (ldpc_kernel.hpp, kPure: the hardware-barrier packed build of the degree class 32): the plain nodes exist for layer 0
+    // only, so EVERY (layer > 0, wave) record has to fit the packed format -- mixed entries within the fix slots, no one-wave walk layer. A
+    // table that does not fit takes the plain build (of the 57 tables this concerns 9/10 normal only, which fits).
+    if (v2 && !soft_bar_ && v2_pure_class(dmax_)) {
+        bool fits = v2p_on;
+        for (int i = 1; fits && i < sched_.q; i++) {
+            const LdpcLayer& L = sched_.layers[i];
+            const int ncv = layer_nc[i];
+            if (L.block < 360 && !((ncv == 2 || ncv == 4 || ncv == 8) && (int)L.cnt >= ncv && v2p_class(dmax_))) { fits = false; break; }
+            for (int w = 0; w < 6 && fits; w++) {
+                const int lo = 64 * w, hi = std::min(64 * w + 63, 359);
+                int nm = 0;
+                for (int k = L.block < 360 ? ncv : 0; k < L.cnt; k++) { const int thr = 360 - (int)sched_.entries[L.entry_off + layer_order[i][k]].rot; nm += lo < thr && thr <= hi; }
+                if (nm > (L.block < 360 ? std::min(dmax_ / 2, (int)L.cnt) - ncv : std::min(dmax_ / 4, (int)L.cnt))) fits = false;
+            }
+        }
+        if (!fits) v2 = false;
+    }
     v2_ = v2;
     const int RSW = rec_stride_wave(dmax_);
     std::vector<uint32_t> wr((size_t)sched_.q * 6 * RSW, 0);
     // single-pair hazard layers walked by the packed register chain (check_node_chain_v2): block <= kChainMaxBlock, the pair are
     // the first two entries (schedule compiler), and on every wave the mixed regular entries fit the fix slots after the pair's
     std::vector<char> chain_v2_layer(sched_.q, 0), chain_order(sched_.q, 0);
-    bool v2p_on = true; // hazard layers with the packed first / last phase (classes from DVBS2_V2P_MIN_DMAX up); DVBS2_V2P=0: experiments, tests
-    if (const char* e = getenv("DVBS2_V2P")) v2p_on = atoi(e) != 0;
     chain_plain_ = false; // plain build + packed chain node (ldpc_kernel.hpp, CHAIN): measured slower, not built (kChainBuilt); experiments only
     if (const char* e = getenv("DVBS2_CHAIN_PLAIN")) chain_plain_ = !pr_ && !dense_ && !v2 && dmax_ <= 16 && atoi(e) != 0;
     bool chain_v2 = (v2 || chain_plain_) && dmax_ <= 16; // the packed chain node is only built for the low degree classes

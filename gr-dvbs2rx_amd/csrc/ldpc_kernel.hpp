@@ -378,6 +378,10 @@ template <int DMAX, bool HZ2> constexpr bool kTlc = (DMAX == 16 || DMAX == 24 ||
 #define DVBS2_V2P_MIN_DMAX 20
 #endif
 __host__ __device__ constexpr bool v2p_class(int dmax) { return dmax >= DVBS2_V2P_MIN_DMAX; }
+#ifndef DVBS2_V2_PURE_MIN_DMAX
+#define DVBS2_V2_PURE_MIN_DMAX 32 // measured (round 5, interleaved A/B): class 32 (9/10 normal) 80.2 -> 83.9 k; 28 (8/9) 95.9 -> 91.2 k, 24 (5/6) 76.9 -> 74.2 k
+#endif
+__host__ __device__ constexpr bool v2_pure_class(int dmax) { return dmax >= DVBS2_V2_PURE_MIN_DMAX; }
 __host__ __device__ constexpr bool tlc_class(int dmax) { return dmax == 16 || dmax == 24 || dmax == 32; }
 constexpr int kTlcLowRegMinDmax = 24; // from this degree class on a two-level-chain layer keeps its regular entries in the low-register form
 __device__ __forceinline__ int pm_pack(int magp, int d) { return (int)__builtin_amdgcn_perm((uint32_t)magp, (uint32_t)d, 0x0c0c0400u); } // d.b0 | magp.b0 << 8
@@ -516,10 +520,17 @@ __device__ __forceinline__ void check_node_v2(const uint32_t* ent /*record words
     constexpr bool ODD = (DEG & 1) != 0;   // the upper half of the last pair is a pad: L = m = 0, magnitude "absent"
     __builtin_amdgcn_s_setprio(0);
     int ad[DEG];
+    auto addresses = [&]() {
 #pragma unroll
-    for (int k = 0; k < DEG; k++) ad[k] = jjb + (int)ent[k];
+        for (int k = 0; k < DEG; k++) ad[k] = jjb + (int)ent[k];
 #pragma unroll
-    for (int k = 0; k < NFIX; k++) ad[k] = fix_wrap(ad[k], ent[DMAX + 2 * k], ent[DMAX + 2 * k + 1]);
+        for (int k = 0; k < NFIX; k++) ad[k] = fix_wrap(ad[k], ent[DMAX + 2 * k], ent[DMAX + 2 * k + 1]);
+    };
+    addresses();
+#ifndef DVBS2_V2_KEEP_AD_MAXDEG
+#define DVBS2_V2_KEEP_AD_MAXDEG 32 // experiments: above this degree the addresses are computed again in the output phase instead of held across the node
+#endif
+    constexpr bool KEEP_AD = DEG <= DVBS2_V2_KEEP_AD_MAXDEG;
     int Lb[DEG];
 #pragma unroll
     for (int k = 0; k < DEG; k++) Lb[k] = lds_rd(ad[k]);
@@ -553,6 +564,7 @@ __device__ __forceinline__ void check_node_v2(const uint32_t* ent /*record words
     const int B0 = n0, B1 = n0 + n1m - n0m, T = n1m + n0;
     const v2s16 B0p = { (short)B0, (short)B0 }, B1p = { (short)B1, (short)B1 }, Tp = { (short)T, (short)T };
     const uint32_t tm = (uint32_t)((int)(sx ^ (sx << 16)) >> 31); // all ones when the number of negative inputs is odd
+    if constexpr (!KEEP_AD) { asm volatile("" ::: "memory"); addresses(); }
     uint32_t R[NP];
 #pragma unroll
     for (int j = 0; j < NP; j++) {
@@ -764,6 +776,10 @@ __device__ __forceinline__ void check_node_chain_v2(const uint32_t* ent /*S0w[DM
 // (moving a regular entry into the ordered part does not change the result).
 // LDS scratch of a lane chain with block size B: (360 + B) per-row records (dwords) + as many log bytes
 __host__ __device__ constexpr int lane_chain_words(int block) { return (kM + block) + (kM + block + 3) / 4; }
+#ifndef DVBS2_LANE_CHAIN_MAXDEG_V2P
+#define DVBS2_LANE_CHAIN_MAXDEG_V2P 32 // the lane chain in hazard nodes with the packed first / last phase (their state is smaller): 9/10 normal 83.9 -> 86.3 k (round 5)
+#endif
+constexpr int kLaneChainMaxDegV2p = DVBS2_LANE_CHAIN_MAXDEG_V2P;
 constexpr int kLaneChainMaxDeg = 28;                                  // not instantiated for the big variants nor for the
                                                                       // 80-VGPR parity-in-records kernel (registers)
 constexpr int kMaxHazard = 8;     // ordered entries per check in the common builds, kMaxHazardHz2 in the HZ2 builds (ldpc_layered_kernel)
@@ -909,7 +925,7 @@ __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, con
     __builtin_amdgcn_s_setprio(3);
     bool lane_chain = false;
     // (the low-register form has room for it at every degree)
-    constexpr bool kLaneChainBuilt = NC == 2 && (LR || DEG <= kLaneChainMaxDeg) && !PR && CHAINOK;
+    constexpr bool kLaneChainBuilt = NC == 2 && (LR || DEG <= (V2P ? kLaneChainMaxDegV2p : kLaneChainMaxDeg)) && !PR && CHAINOK;
     if constexpr (kLaneChainBuilt) lane_chain = tab != nullptr; // wave-uniform (header bit 12)
     if constexpr (kLaneChainBuilt) if (lane_chain) {
         // LANE CHAIN (one hazard pair, block <= 128, host-ordered so that entry 0's bit of row r is entry 1's bit of
@@ -1417,7 +1433,7 @@ __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, con
 // degrees DMAX-7 .. DMAX are instantiated for kernel variant DMAX
 #define DVBS2_DEG_CASE(D) case D: if constexpr (D >= 3 && D <= DMAX && D > DMAX - 8) { \
         if constexpr (kLowReg<DMAX, HZ2>) { if (layer0) check_node_lr<(D >= 3 ? D : 3), true>(ent, jj, lb, mw, nm); else check_node_lr<(D >= 3 ? D : 3), false>(ent, jj, lb, mw, nm); } \
-        else { if (layer0) check_node<(D >= 3 ? D : 3), true>(lds_all, ent, jj, lb, mw, nm); else check_node<(D >= 3 ? D : 3), false>(lds_all, ent, jj, lb, mw, nm); } } break;
+        else { if (layer0) check_node<(D >= 3 ? D : 3), true>(lds_all, ent, jj, lb, mw, nm); else { if constexpr (!kPure) check_node<(D >= 3 ? D : 3), false>(lds_all, ent, jj, lb, mw, nm); } } } break;
 #define DVBS2_DEG_SWITCH switch (deg) { \
         DVBS2_DEG_CASE(3) DVBS2_DEG_CASE(4) DVBS2_DEG_CASE(5) DVBS2_DEG_CASE(6) DVBS2_DEG_CASE(7) DVBS2_DEG_CASE(8) \
         DVBS2_DEG_CASE(9) DVBS2_DEG_CASE(10) DVBS2_DEG_CASE(11) DVBS2_DEG_CASE(12) DVBS2_DEG_CASE(13) DVBS2_DEG_CASE(14) \
@@ -1449,7 +1465,7 @@ __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, con
 // state made the compiler spill the regular entries of EVERY four- and eight-entry layer around it, 9/10 normal's multi-pair
 // layers went from 12-17 k to 25-34 k cycles.)
 #define DVBS2_HAZ_CALL1(D, NCV, LRV, TLCV) { \
-        if (layer0) check_node_hazard<D, NCV, true, false, false, HZ2, LRV, TLCV, (MINW == 1), (DMAX <= 8)>(lds_all, ent, jj, lb, work, block, block2, mw, nm, 0, nullptr, htab, hb_ctr, hb_epoch, hb_lane, hz_ph); else check_node_hazard<D, NCV, false, false, false, HZ2, LRV, TLCV, (MINW == 1), (DMAX <= 8)>(lds_all, ent, jj, lb, work, block, block2, mw, nm, 0, nullptr, htab, hb_ctr, hb_epoch, hb_lane, hz_ph); }
+        if (layer0) check_node_hazard<D, NCV, true, false, false, HZ2, LRV, TLCV, (MINW == 1), (DMAX <= 8)>(lds_all, ent, jj, lb, work, block, block2, mw, nm, 0, nullptr, htab, hb_ctr, hb_epoch, hb_lane, hz_ph); else { if constexpr (!kPure) check_node_hazard<D, NCV, false, false, false, HZ2, LRV, TLCV, (MINW == 1), (DMAX <= 8)>(lds_all, ent, jj, lb, work, block, block2, mw, nm, 0, nullptr, htab, hb_ctr, hb_epoch, hb_lane, hz_ph); } }
 #define DVBS2_HAZ_CALL(D, NCV) { if constexpr (D - 2 >= NCV) { \
         if constexpr (kTlc<DMAX, HZ2> && (!SOFT || DVBS2_TLC_SOFT) && MINW == 1 && (NCV == 4 || NCV == 8)) { if (block2 > 0 && htab != nullptr) DVBS2_HAZ_CALL1(D, NCV, (DMAX >= kTlcLowRegMinDmax), true) else DVBS2_HAZ_CALL1(D, NCV, (kLowReg<DMAX, HZ2>), false) } \
         else DVBS2_HAZ_CALL1(D, NCV, (kLowReg<DMAX, HZ2>), false) } }
@@ -1548,6 +1564,10 @@ __global__ __launch_bounds__(SOLO ? kSoloThreads : kThreads, SOLO ? 4 : MINW) vo
     constexpr int RS = rec_stride(DMAX);
     constexpr int RSW = V2 ? 6 * rec_stride_wave(DMAX) : rec_stride(DMAX); // dwords from one layer's sweep record to the next
     constexpr int MW = DMAX / 4; // message dwords per check (fixed per kernel variant)
+    // "pure" packed builds (DVBS2_V2_PURE_MIN_DMAX; hardware barriers only): the plain nodes are compiled for layer 0 only -- the plain hazard
+    // nodes of the degree class 32 cost the packed ones around them 5 % through register allocation --; the host runs such a build only
+    // for tables whose every (layer > 0, wave) record fits the packed format (ldpc_hip.hip)
+    constexpr bool kPure = V2 && !SOFT && v2_pure_class(DMAX);
     int solo_tid = (int)threadIdx.x;
     int solo_slot = -1, solo_pat = 0;
     if constexpr (SOLO) {
