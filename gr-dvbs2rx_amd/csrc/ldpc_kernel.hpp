@@ -203,6 +203,19 @@ __device__ __forceinline__ int mag_offset(int Lb, int mb)
 // array's address is a link-time constant the compiler cannot fold into an address that inline asm produced.
 __device__ __forceinline__ int lds_rd(int a) { return *reinterpret_cast<const lds_byte_t*>((size_t)(uint32_t)a); }
 __device__ __forceinline__ void lds_wr(int a, int v) { *reinterpret_cast<lds_byte_t*>((size_t)(uint32_t)a) = (uint8_t)v; }
+// Round 5: the builds with packed nodes keep the LLR bytes in LDS as TWO'S COMPLEMENT (TC): the packed arithmetic works on value << 8 in signed
+// 16-bit halves, and with offset-binary bytes every pair paid one xor after its reads and one before its writes (8 of the ~110 VALU instructions
+// of a degree-7 check). The scalar paths of such a build (layer 0, the ordered phase of hazard layers, waves whose record does not fit the
+// packed format) convert at their LDS accesses; messages, the state in HBM and every other build stay as they were.
+// Measured (interleaved A/B, all packed builds with and without): the degree class 8 gains (B4 135.4 -> 137.7 k, S2X 9/20 +0.7 %), every other
+// class loses 0.2-3 % (3/4 normal -2.7 %, 4/5 -3 %, short 3/4 -2.9 %: their scalar paths pay the conversion, and removing 7 % of the packed
+// node's VALU instructions buys almost nothing where the layer is as much bound by its message traffic and barriers) -- so: class 8 only.
+#ifndef DVBS2_TC_MAX_DMAX
+#define DVBS2_TC_MAX_DMAX 8
+#endif
+template <bool TC> __device__ __forceinline__ int lds_rdx(int a) { const int v = lds_rd(a); return TC ? (v ^ 0x80) : v; }          // offset-binary value of the LLR byte at a
+template <bool TC> __device__ __forceinline__ void lds_wrx(int a, int v) { lds_wr(a, TC ? (v ^ 0x80) : v); }                        // store an offset-binary value
+template <bool TC> constexpr uint32_t kObPair = TC ? 0u : 0x80008000u; // offset binary -> two's complement << 8 of a pair register
 __device__ __forceinline__ int lds_address_of(const uint8_t* p) { return (int)(uint32_t)(size_t)(const lds_byte_t*)p; }
 
 // LDS address of check row jj for entry (S0 = 360*g + rot, thr = 360 - rot): S0 + jj, minus 360 when jj >= thr.
@@ -272,7 +285,7 @@ __device__ __forceinline__ uint32_t pack4_lo8(int a, int b, int c, int d)
 // own-parity link produced one layer ago), the new own-parity LLR becomes the carry and the new previous-parity
 // LLR is returned in byte 7 of this layer's record. Only row q-1 (own parity of the LAST layer, previous
 // parity of layer 0 shifted by one lane) stays in LDS.
-template <int DEG, bool LAYER0, bool PR = false, bool LAST = false>
+template <int DEG, bool LAYER0, bool PR = false, bool LAST = false, bool TC = false>
 __device__ __forceinline__ void check_node(uint8_t* __restrict__ lds /*the whole LDS array*/, const uint32_t* ent /*uniform: S0, thr pairs*/,
                                            int jj, int lb /*byte offset of this frame's region*/, const uint32_t* mw, uint32_t* nm,
                                            int own_in = 0, int* carry = nullptr)
@@ -297,7 +310,7 @@ __device__ __forceinline__ void check_node(uint8_t* __restrict__ lds /*the whole
     for (int k = 0; k < DEG; k++) {
         if (OWN_REG && k == DEG - 2) Lb[k] = own_in;
         else if (PREV_REG && k == DEG - 1) Lb[k] = *carry;
-        else Lb[k] = lds_rd(ad[k]);
+        else Lb[k] = lds_rdx<TC>(ad[k]);
     }
     // check (0,0) has no previous-parity link (layered_decoder.hh:56,63-66)
     const bool last_valid = !LAYER0 || jj != 0;
@@ -333,7 +346,7 @@ __device__ __forceinline__ void check_node(uint8_t* __restrict__ lds /*the whole
         const int nl = sat_sum_u8(inp[k], out);
         if (OWN_REG && k == DEG - 2) *carry = nl;
         else if (PREV_REG && k == DEG - 1) spare = nl;
-        else if (!(LAYER0 && k == DEG - 1) || last_valid) lds_wr(ad[k], nl);
+        else if (!(LAYER0 && k == DEG - 1) || last_valid) lds_wrx<TC>(ad[k], nl);
         msgc[k] = min(max(out, -32), 31);
     }
     __builtin_amdgcn_s_setprio(3);
@@ -511,7 +524,7 @@ __device__ __forceinline__ void msg_pack16(const uint32_t* R /*clamped messages 
 // words of one check's message record that hold fields, and whether word k is a 16-bit access, for degree deg
 __host__ __device__ constexpr int p6_fields(int deg, int k) { return deg - 5 * k < 0 ? 0 : (deg - 5 * k > 5 ? 5 : deg - 5 * k); }
 
-template <int DEG, int DMAX, bool P6, class Prefetch>
+template <int DEG, int DMAX, bool P6, bool TC, class Prefetch>
 __device__ __forceinline__ void check_node_v2(const uint32_t* ent /*record words 4..: S0w[DMAX], then (mask lo, mask hi)[NFIX]*/,
                                               int jjb, const uint32_t* mw, uint32_t* nm, Prefetch prefetch_next_record)
 {
@@ -539,8 +552,8 @@ __device__ __forceinline__ void check_node_v2(const uint32_t* ent /*record words
 #pragma unroll
     for (int j = 0; j < NP; j++) {
         const uint32_t M = msg_pair16<P6>(mw, j); // messages of pair j: << 8 in both halves
-        const uint32_t hi = (ODD && j == NP - 1) ? 0x80u : (uint32_t)Lb[2 * j + 1];
-        const uint32_t L = __builtin_amdgcn_perm(hi, (uint32_t)Lb[2 * j], 0x040c000cu) ^ 0x80008000u; // offset binary -> two's complement << 8
+        const uint32_t hi = (ODD && j == NP - 1) ? (TC ? 0x00u : 0x80u) : (uint32_t)Lb[2 * j + 1];
+        const uint32_t L = __builtin_amdgcn_perm(hi, (uint32_t)Lb[2 * j], 0x040c000cu) ^ kObPair<TC>; // -> two's complement << 8
         d[j] = __builtin_elementwise_sub_sat(as_v2s(L), as_v2s(M));           // R1 (a half that saturates upwards reads 0x7fff)
         sx ^= as_u32(d[j]);                                                   // R4: bits 15 and 31 collect the signs
         a[j] = __builtin_elementwise_max(d[j], __builtin_elementwise_sub_sat(as_v2s(0u), d[j])); // |inp| << 8 (0x7fff for -128 and for saturated halves)
@@ -574,7 +587,7 @@ __device__ __forceinline__ void check_node_v2(const uint32_t* ent /*record words
         const v2s16 sg = as_v2s(as_u32(d[j]) ^ tm) >> (v2s16){ 15, 15 };
         const v2s16 out = as_v2s(as_u32(other) ^ as_u32(sg)) - sg;
         // R6: LLR = sat8(inp + out); the low byte of a half never reaches the byte that is stored
-        const uint32_t nl = (as_u32(__builtin_elementwise_add_sat(d[j], out)) ^ 0x80008000u) >> 8;
+        const uint32_t nl = (as_u32(__builtin_elementwise_add_sat(d[j], out)) ^ kObPair<TC>) >> 8;
         lds_wr(ad[2 * j], (int)nl);
         if (!(ODD && j == NP - 1)) lds_wr_hi(ad[2 * j + 1], nl);
         // R7
@@ -603,7 +616,7 @@ __device__ __forceinline__ float as_f32(uint32_t x) { return __builtin_bit_cast(
 __device__ __forceinline__ float vmed3_f32(float a, float b, float c) { return __builtin_amdgcn_fmed3f(a, b, c); }
 __device__ __forceinline__ float byte1_f32(uint32_t x) { return (float)((x >> 8) & 0xffu); } // v_cvt_f32_ubyte1
 
-template <int DEG, int DMAX, bool P6>
+template <int DEG, int DMAX, bool P6, bool TC>
 __device__ __forceinline__ void check_node_chain_v2(const uint32_t* ent /*S0w[DMAX], masks[NFIX + 2]*/, int jj, int jjb, bool work, int B,
                                                     const uint32_t* mw, uint32_t* nm, lds_u32_t* tab /*LDS scratch, 16-byte aligned*/,
                                                     volatile lds_i32_t* hb_ctr, int& hb_epoch, const int hb_lane)
@@ -630,8 +643,8 @@ __device__ __forceinline__ void check_node_chain_v2(const uint32_t* ent /*S0w[DM
 #pragma unroll
         for (int k = 0; k < NFIXH; k++) ad[k] = fix_wrap(ad[k], ent[DMAX + 2 * k], ent[DMAX + 2 * k + 1]);
     };
-    auto pair0 = [&](int LbX, int LbY) { // d, |d| of the pair [X | Y]
-        const uint32_t L = __builtin_amdgcn_perm((uint32_t)LbY, (uint32_t)LbX, 0x040c000cu) ^ 0x80008000u;
+    auto pair0 = [&](int LbX, int LbY) { // d, |d| of the pair [X | Y] (LLR bytes as they lie in LDS)
+        const uint32_t L = __builtin_amdgcn_perm((uint32_t)LbY, (uint32_t)LbX, 0x040c000cu) ^ kObPair<TC>;
         const uint32_t M = msg_pair16<P6>(mw, 0);
         d[0] = __builtin_elementwise_sub_sat(as_v2s(L), as_v2s(M));
         a[0] = __builtin_elementwise_max(d[0], __builtin_elementwise_sub_sat(as_v2s(0u), d[0]));
@@ -647,8 +660,8 @@ __device__ __forceinline__ void check_node_chain_v2(const uint32_t* ent /*S0w[DM
 #pragma unroll
         for (int j = 1; j < NP; j++) {
             const uint32_t M = msg_pair16<P6>(mw, j);
-            const uint32_t hi = (ODD && j == NP - 1) ? 0x80u : (uint32_t)Lb[2 * j + 1];
-            const uint32_t L = __builtin_amdgcn_perm(hi, (uint32_t)Lb[2 * j], 0x040c000cu) ^ 0x80008000u;
+            const uint32_t hi = (ODD && j == NP - 1) ? (TC ? 0x00u : 0x80u) : (uint32_t)Lb[2 * j + 1];
+            const uint32_t L = __builtin_amdgcn_perm(hi, (uint32_t)Lb[2 * j], 0x040c000cu) ^ kObPair<TC>;
             d[j] = __builtin_elementwise_sub_sat(as_v2s(L), as_v2s(M));
             sxp ^= as_u32(d[j]);
             a[j] = __builtin_elementwise_max(d[j], __builtin_elementwise_sub_sat(as_v2s(0u), d[j]));
@@ -668,14 +681,15 @@ __device__ __forceinline__ void check_node_chain_v2(const uint32_t* ent /*S0w[DM
             const uint32_t ds = __builtin_amdgcn_alignbit(as_u32(d[0]), as_u32(d[0]), 16);
             const v2s16 sg = as_v2s(ds ^ par) >> (v2s16){ 15, 15 };
             const v2s16 out = as_v2s(as_u32(other) ^ as_u32(sg)) - sg;
-            const uint32_t nl = as_u32(__builtin_elementwise_add_sat(d[0], out)) ^ 0x80008000u; // offset binary in bytes 1 and 3
-            lds_wr_hi(ad[1], nl >> 8);                                 // Y now (a tail row reads it as its X)
+            const uint32_t raw = as_u32(__builtin_elementwise_add_sat(d[0], out));
+            const uint32_t nl = raw ^ 0x80008000u;                      // offset binary in bytes 1 and 3 (the chain walks offset-binary values)
+            lds_wr_hi(ad[1], (TC ? raw : nl) >> 8);                    // Y now (a tail row reads it as its X)
             c = byte1_f32(nl);                   // X starts the chain
         }
     }
     // chain operands of the middle rows (a tail row only receives: the walker logs what arrives there and needs nothing from it)
     if (middle) {
-        const uint32_t L = __builtin_amdgcn_perm(0x80u, (uint32_t)LbX, 0x040c000cu) ^ 0x80008000u;
+        const uint32_t L = __builtin_amdgcn_perm(TC ? 0x00u : 0x80u, (uint32_t)LbX, 0x040c000cu) ^ kObPair<TC>;
         const uint32_t M0 = msg_pair16<P6>(mw, 0);
         const uint32_t M = M0 & 0x0000ffffu;
         const v2s16 dx = __builtin_elementwise_sub_sat(as_v2s(L), as_v2s(M));       // [inp_X | 0]
@@ -727,7 +741,7 @@ __device__ __forceinline__ void check_node_chain_v2(const uint32_t* ent /*S0w[DM
         if constexpr (!KEEP_AD) addresses();
         if (body) {
             if (!middle) LbX = lds_rd(ad[0]); // tail: the Y value its head wrote in the first phase
-            pair0(LbX, (int)logv[jj]);
+            pair0(LbX, (int)logv[jj] ^ (TC ? 0x80 : 0)); // (the log holds the chain's offset-binary values)
         }
         sxp ^= as_u32(d[0]);
         int m4[4] = { p0, p1, (int)(as_u32(a[0]) & 0xffffu), (int)(as_u32(a[0]) >> 16) };
@@ -746,7 +760,7 @@ __device__ __forceinline__ void check_node_chain_v2(const uint32_t* ent /*S0w[DM
             const v2s16 other = Tp - cl;
             const v2s16 sg = as_v2s(as_u32(d[j]) ^ tm) >> (v2s16){ 15, 15 };
             const v2s16 out = as_v2s(as_u32(other) ^ as_u32(sg)) - sg;
-            const uint32_t nl = (as_u32(__builtin_elementwise_add_sat(d[j], out)) ^ 0x80008000u) >> 8;
+            const uint32_t nl = (as_u32(__builtin_elementwise_add_sat(d[j], out)) ^ kObPair<TC>) >> 8;
             if (j == 0) {
                 if (jj + B >= kM) lds_wr(ad[0], (int)nl);   // a tail row is the last writer of its X bit (the others handed X down the chain)
                 if (body) lds_wr_hi(ad[1], nl);             // heads wrote Y in P1 (by now a tail row may have replaced it)
@@ -794,7 +808,7 @@ template <int DEG, int NC, bool LAYER0, bool PR = false, bool LAST = false, bool
           bool V2P = false /*round 5: FIRST and LAST phase in the packed form of check_node_v2 (pairs of regular entries in the halves of one
                              register, one-add addresses from this wave's record, two's complement messages in pair-byte order); the ordered
                              phase in between is untouched. `ent` is then the per-wave record: S0w[DMAXV], lane masks of the first NFIXH slots*/,
-          int DMAXV = 0, bool P6 = false>
+          int DMAXV = 0, bool P6 = false, bool TC = false /*LLR bytes in LDS are two's complement (the builds with packed nodes)*/>
 __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, const uint32_t* ent, int jj, int lb, bool work,
                                                   int block, int block2 /*two-level walk: rows per outer block, 0 = off*/, const uint32_t* mw, uint32_t* nm, int own_in, int* carry,
                                                   lds_u32_t* tab /*lane_chain_words(block) of LDS scratch when the layer is a lane chain*/,
@@ -848,8 +862,8 @@ __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, con
 #pragma unroll
             for (int j = NPH; j < NP; j++) {
                 const uint32_t M = msg_pair16<P6>(mw, j);
-                const uint32_t hi = (ODD && j == NP - 1) ? 0x80u : (uint32_t)Lb[2 * j + 1];
-                const uint32_t L = __builtin_amdgcn_perm(hi, (uint32_t)Lb[2 * j], 0x040c000cu) ^ 0x80008000u;
+                const uint32_t hi = (ODD && j == NP - 1) ? (TC ? 0x00u : 0x80u) : (uint32_t)Lb[2 * j + 1];
+                const uint32_t L = __builtin_amdgcn_perm(hi, (uint32_t)Lb[2 * j], 0x040c000cu) ^ kObPair<TC>;
                 dP[j] = __builtin_elementwise_sub_sat(as_v2s(L), as_v2s(M));
                 sxp ^= as_u32(dP[j]);
                 aP[j] = __builtin_elementwise_max(dP[j], __builtin_elementwise_sub_sat(as_v2s(0u), dP[j]));
@@ -868,7 +882,7 @@ __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, con
             for (int k = 0; k < NC; k++) ad[k] = addr(k);
 #pragma unroll
             for (int k = NC; k < DEG; k++) {
-                const int Lb = lds_rd(addr(k));
+                const int Lb = lds_rdx<TC>(addr(k));
                 const int mb = (int)((mw[k >> 2] >> (8 * (k & 3))) & 0xffu);
                 int d = min(max(Lb - mb, -128), 127);
                 const int magp = (int)__builtin_amdgcn_sad_u16((uint32_t)Lb, (uint32_t)mb, 0u);
@@ -888,9 +902,9 @@ __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, con
         }
 #pragma unroll
         for (int k = 0; k < DEG; k++) {
-            if (kEarlyPair && k < 2) Lh01[k] = lds_rd(ad[k]); // (see the lane chain below: issued with the regular reads, used only where still valid)
+            if (kEarlyPair && k < 2) Lh01[k] = lds_rdx<TC>(ad[k]); // (see the lane chain below: issued with the regular reads, used only where still valid)
             if (k >= NC) { // regular entry
-                const int Lb = (OWN_REG && k == DEG - 2) ? own_in : (PREV_REG && k == DEG - 1) ? *carry : lds_rd(ad[k]);
+                const int Lb = (OWN_REG && k == DEG - 2) ? own_in : (PREV_REG && k == DEG - 1) ? *carry : lds_rdx<TC>(ad[k]);
                 const int mb = (int)((mw[k >> 2] >> (8 * (k & 3))) & 0xffu);
                 int d = min(max(Lb - mb, -128), 127);
                 int mag = mag_raw(Lb, mb);
@@ -975,12 +989,12 @@ __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, con
         constexpr bool kTwoBarrier = LR || DEG <= 20;
         const bool orig0 = work && (kTwoBarrier ? jj + block < kM : jj < block); // entry 0 still holds its value from before the layer (every head is one: block <= 128)
         if (orig0) {
-            const int L0 = kEarlyPair ? Lh01[0] : lds_rd(ad[0]);
+            const int L0 = kEarlyPair ? Lh01[0] : lds_rdx<TC>(ad[0]);
             inp[0] = min(max(L0 - hmb[0], -128), 127);
             mg[0] = mag_raw(L0, hmb[0]);
         }
         if (head) {
-            const int L1 = kEarlyPair ? Lh01[1] : lds_rd(ad[1]);
+            const int L1 = kEarlyPair ? Lh01[1] : lds_rdx<TC>(ad[1]);
             inp[1] = min(max(L1 - hmb[1], -128), 127);
             mg[1] = mag_raw(L1, hmb[1]);
             int o0, o1;
@@ -990,13 +1004,13 @@ __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, con
             hout[0] = (o0 ^ s0) - s0;
             hout[1] = (o1 ^ s1) - s1;
             chained = sat_sum_u8(inp[0], hout[0]);
-            lds_wr(ad[1], sat_sum_u8(inp[1], hout[1]));
+            lds_wrx<TC>(ad[1], sat_sum_u8(inp[1], hout[1]));
         } else if (kTwoBarrier && orig0)
             publish();
         if constexpr (!kTwoBarrier) {
             lds_barrier();
             if (body) { // every row below the heads, tails included (their entry 0 is what a head just wrote)
-                const int L0 = lds_rd(ad[0]);
+                const int L0 = lds_rdx<TC>(ad[0]);
                 inp[0] = min(max(L0 - hmb[0], -128), 127);
                 mg[0] = mag_raw(L0, hmb[0]);
                 publish();
@@ -1085,7 +1099,7 @@ __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, con
         DVBS2_PH(5); // barrier after the walk
         if (body) {
             if (kTwoBarrier && !orig0) { // tail: entry 0 = the entry-1 value its head wrote before the walk
-                const int L0 = lds_rd(ad[0]);
+                const int L0 = lds_rdx<TC>(ad[0]);
                 inp[0] = min(max(L0 - hmb[0], -128), 127);
                 mg[0] = mag_raw(L0, hmb[0]);
             }
@@ -1098,8 +1112,8 @@ __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, con
             const int s0 = (signs ^ inp[1]) >> 31, s1 = (signs ^ inp[0]) >> 31;
             hout[0] = (o0 ^ s0) - s0;
             hout[1] = (o1 ^ s1) - s1;
-            lds_wr(ad[1], sat_sum_u8(inp[1], hout[1]));
-            if (jj + block >= kM) lds_wr(ad[0], sat_sum_u8(inp[0], hout[0]));
+            lds_wrx<TC>(ad[1], sat_sum_u8(inp[1], hout[1]));
+            if (jj + block >= kM) lds_wrx<TC>(ad[0], sat_sum_u8(inp[0], hout[0]));
         }
     }
     // TWO-LEVEL LANE CHAIN (NC >= 4, block2 > 0, header bit 12; degree class 32 without the heavy-hazard paths). As in the two-level
@@ -1131,8 +1145,8 @@ __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, con
             if (in_sb) {
                 int Lh[NC];
 #pragma unroll
-                for (int k = 2; k < NC; k++) Lh[k] = lds_rd(ad[k]);
-                const int L0 = lds_rd(ad[0]);
+                for (int k = 2; k < NC; k++) Lh[k] = lds_rdx<TC>(ad[k]);
+                const int L0 = lds_rdx<TC>(ad[0]);
 #pragma unroll
                 for (int k = 2; k < NC; k++) {
                     inp[k] = min(max(Lh[k] - hmb[k], -128), 127);
@@ -1143,7 +1157,7 @@ __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, con
                 inp[0] = min(max(L0 - hmb[0], -128), 127);
                 mg[0] = mag_raw(L0, hmb[0]);
                 if (head) { // (first outer block: block2 >= 2 block)
-                    const int L1 = lds_rd(ad[1]);
+                    const int L1 = lds_rdx<TC>(ad[1]);
                     inp[1] = min(max(L1 - hmb[1], -128), 127);
                     mg[1] = mag_raw(L1, hmb[1]);
                     int o0, o1;
@@ -1153,7 +1167,7 @@ __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, con
                     hout[0] = (o0 ^ s0) - s0;
                     hout[1] = (o1 ^ s1) - s1;
                     chained = sat_sum_u8(inp[0], hout[0]);
-                    lds_wr(ad[1], sat_sum_u8(inp[1], hout[1]));
+                    lds_wrx<TC>(ad[1], sat_sum_u8(inp[1], hout[1]));
                 } else
                     tab[jj] = ((uint32_t)inp[0] & 0x1ffu) | ((uint32_t)minF << 9) | (((uint32_t)signsF >> 31) << 16) | ((uint32_t)hmb[1] << 24);
             }
@@ -1186,8 +1200,8 @@ __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, con
                     const int s0 = (signsF ^ inp[1]) >> 31, s1 = (signsF ^ inp[0]) >> 31;
                     hout[0] = (o0 ^ s0) - s0;
                     hout[1] = (o1 ^ s1) - s1;
-                    lds_wr(ad[1], sat_sum_u8(inp[1], hout[1]));
-                    if (jj + block >= kM) lds_wr(ad[0], sat_sum_u8(inp[0], hout[0])); // last row of its chain: final writer of that bit
+                    lds_wrx<TC>(ad[1], sat_sum_u8(inp[1], hout[1]));
+                    if (jj + block >= kM) lds_wrx<TC>(ad[0], sat_sum_u8(inp[0], hout[0])); // last row of its chain: final writer of that bit
                 }
                 mg[0] = clamp_mag(mg[0]); mg[1] = clamp_mag(mg[1]); // (raw above; everything below and after the loop takes clamped ones)
                 const int xall = signsF ^ inp[0] ^ inp[1];
@@ -1203,7 +1217,7 @@ __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, con
                     const int sg = (xall ^ inp[k]) >> 31;
                     const int out = (other ^ sg) - sg;
                     hout[k] = out;
-                    lds_wr(ad[k], sat_sum_u8(inp[k], out));
+                    lds_wrx<TC>(ad[k], sat_sum_u8(inp[k], out));
                 }
             }
             if (sb + block2 < kM) lds_barrier(); // the next outer block reads what this one wrote
@@ -1227,7 +1241,7 @@ __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, con
             if (in_sb) {
                 int Lh[NC];
 #pragma unroll
-                for (int k = 2; k < NC; k++) Lh[k] = lds_rd(ad[k]);
+                for (int k = 2; k < NC; k++) Lh[k] = lds_rdx<TC>(ad[k]);
 #pragma unroll
                 for (int k = 2; k < NC; k++) {
                     inp[k] = min(max(Lh[k] - hmb[k], -128), 127);
@@ -1240,7 +1254,7 @@ __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, con
             int rel = in_sb ? jj - sb : 0x40000000;
             for (int start = sb; start < sb_end; start += block, rel -= block) {
                 if ((uint32_t)rel < (uint32_t)block) {
-                    const int L0 = lds_rd(ad[0]), L1 = lds_rd(ad[1]);
+                    const int L0 = lds_rdx<TC>(ad[0]), L1 = lds_rdx<TC>(ad[1]);
                     inp[0] = min(max(L0 - hmb[0], -128), 127);
                     inp[1] = min(max(L1 - hmb[1], -128), 127);
                     mg[0] = mag_offset(L0, hmb[0]);
@@ -1249,8 +1263,8 @@ __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, con
                     const int s0 = (signsF ^ inp[1]) >> 31, s1 = (signsF ^ inp[0]) >> 31;
                     hout[0] = (o0 ^ s0) - s0;
                     hout[1] = (o1 ^ s1) - s1;
-                    lds_wr(ad[0], sat_sum_u8(inp[0], hout[0]));
-                    lds_wr(ad[1], sat_sum_u8(inp[1], hout[1]));
+                    lds_wrx<TC>(ad[0], sat_sum_u8(inp[0], hout[0]));
+                    lds_wrx<TC>(ad[1], sat_sum_u8(inp[1], hout[1]));
                 }
                 if (start + block < sb_end && (start >> 6) != ((start + 2 * block - 1) >> 6)) lds_barrier();
             }
@@ -1268,7 +1282,7 @@ __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, con
                     const int sg = (xall ^ inp[k]) >> 31;
                     const int out = (other ^ sg) - sg;
                     hout[k] = out;
-                    lds_wr(ad[k], sat_sum_u8(inp[k], out));
+                    lds_wrx<TC>(ad[k], sat_sum_u8(inp[k], out));
                 }
             }
             // the next outer block reads what this one wrote: a barrier, unless both sit inside one and the same wavefront
@@ -1285,7 +1299,7 @@ __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, con
             if constexpr (NC == 2) {
                 // two hazard entries: each one's magnitude sent back is min(partial min0, the other's magnitude) =
                 // med3(raw other, 0, min0) (min0 is already clamped to [0, 126])
-                const int L0 = lds_rd(ad[0]), L1 = lds_rd(ad[1]);
+                const int L0 = lds_rdx<TC>(ad[0]), L1 = lds_rdx<TC>(ad[1]);
                 inp[0] = min(max(L0 - hmb[0], -128), 127);
                 inp[1] = min(max(L1 - hmb[1], -128), 127);
                 mg[0] = mag_raw(L0, hmb[0]);
@@ -1296,12 +1310,12 @@ __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, con
                 const int s0 = (signs ^ inp[1]) >> 31, s1 = (signs ^ inp[0]) >> 31;
                 hout[0] = (o0 ^ s0) - s0;
                 hout[1] = (o1 ^ s1) - s1;
-                lds_wr(ad[0], sat_sum_u8(inp[0], hout[0]));
-                lds_wr(ad[1], sat_sum_u8(inp[1], hout[1]));
+                lds_wrx<TC>(ad[0], sat_sum_u8(inp[0], hout[0]));
+                lds_wrx<TC>(ad[1], sat_sum_u8(inp[1], hout[1]));
             } else {
             int Lh[NC];
 #pragma unroll
-            for (int k = 0; k < NC; k++) Lh[k] = lds_rd(ad[k]);
+            for (int k = 0; k < NC; k++) Lh[k] = lds_rdx<TC>(ad[k]);
             int xall = signs;
 #pragma unroll
             for (int k = 0; k < NC; k++) {
@@ -1321,7 +1335,7 @@ __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, con
                 const int sg = (xall ^ inp[k]) >> 31;
                 const int out = (other ^ sg) - sg;
                 hout[k] = out;
-                lds_wr(ad[k], sat_sum_u8(inp[k], out));
+                lds_wrx<TC>(ad[k], sat_sum_u8(inp[k], out));
             }
             }
         }
@@ -1364,7 +1378,7 @@ __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, con
                 const v2s16 sg = as_v2s(as_u32(dP[j]) ^ tm) >> (v2s16){ 15, 15 };
                 const v2s16 out = as_v2s(as_u32(other) ^ as_u32(sg)) - sg;
                 if (j >= NPH) {
-                    const uint32_t nl = (as_u32(__builtin_elementwise_add_sat(dP[j], out)) ^ 0x80008000u) >> 8;
+                    const uint32_t nl = (as_u32(__builtin_elementwise_add_sat(dP[j], out)) ^ kObPair<TC>) >> 8;
                     lds_wr(ad[2 * j], (int)nl);
                     if (!(ODD && j == NP - 1)) lds_wr_hi(ad[2 * j + 1], nl);
                 }
@@ -1405,7 +1419,7 @@ __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, con
                 const int sg = (signs ^ ip) >> 31;
                 const int out = (other ^ sg) - sg;
                 const int nl = sat_sum_u8(ip, out);
-                if (!(LAYER0 && k == DEG - 1) || last_valid) lds_wr(addr(k), nl);
+                if (!(LAYER0 && k == DEG - 1) || last_valid) lds_wrx<TC>(addr(k), nl);
                 nm[k >> 2] |= (uint32_t)(min(max(out, -32), 31) + 128) << (8 * (k & 3));
             }
         }
@@ -1420,7 +1434,7 @@ __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, con
                 const int nl = sat_sum_u8(inp[k], out);
                 if (OWN_REG && k == DEG - 2) *carry = nl;
                 else if (PREV_REG && k == DEG - 1) spare = nl;
-                else if (!(LAYER0 && k == DEG - 1) || last_valid) lds_wr(ad[k], nl);
+                else if (!(LAYER0 && k == DEG - 1) || last_valid) lds_wrx<TC>(ad[k], nl);
                 nm[k >> 2] |= (uint32_t)(min(max(out, -32), 31) + 128) << (8 * (k & 3));
             }
         }
@@ -1433,7 +1447,7 @@ __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, con
 // degrees DMAX-7 .. DMAX are instantiated for kernel variant DMAX
 #define DVBS2_DEG_CASE(D) case D: if constexpr (D >= 3 && D <= DMAX && D > DMAX - 8) { \
         if constexpr (kLowReg<DMAX, HZ2>) { if (layer0) check_node_lr<(D >= 3 ? D : 3), true>(ent, jj, lb, mw, nm); else check_node_lr<(D >= 3 ? D : 3), false>(ent, jj, lb, mw, nm); } \
-        else { if (layer0) check_node<(D >= 3 ? D : 3), true>(lds_all, ent, jj, lb, mw, nm); else { if constexpr (!kPure) check_node<(D >= 3 ? D : 3), false>(lds_all, ent, jj, lb, mw, nm); } } } break;
+        else { if (layer0) check_node<(D >= 3 ? D : 3), true, false, false, TC>(lds_all, ent, jj, lb, mw, nm); else { if constexpr (!kPure) check_node<(D >= 3 ? D : 3), false, false, false, TC>(lds_all, ent, jj, lb, mw, nm); } } } break;
 #define DVBS2_DEG_SWITCH switch (deg) { \
         DVBS2_DEG_CASE(3) DVBS2_DEG_CASE(4) DVBS2_DEG_CASE(5) DVBS2_DEG_CASE(6) DVBS2_DEG_CASE(7) DVBS2_DEG_CASE(8) \
         DVBS2_DEG_CASE(9) DVBS2_DEG_CASE(10) DVBS2_DEG_CASE(11) DVBS2_DEG_CASE(12) DVBS2_DEG_CASE(13) DVBS2_DEG_CASE(14) \
@@ -1442,7 +1456,7 @@ __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, con
         DVBS2_DEG_CASE(27) DVBS2_DEG_CASE(28) DVBS2_DEG_CASE(29) DVBS2_DEG_CASE(30) DVBS2_DEG_CASE(31) DVBS2_DEG_CASE(32) \
         default: break; }
 
-#define DVBS2_V2_CASE(D) case D: if constexpr (D >= 3 && D <= DMAX && D > DMAX - 8) { check_node_v2<(D >= 3 ? D : 3), DMAX, P6>(ent, jj + lb, mw, nm, prefetch); } break;
+#define DVBS2_V2_CASE(D) case D: if constexpr (D >= 3 && D <= DMAX && D > DMAX - 8) { check_node_v2<(D >= 3 ? D : 3), DMAX, P6, TC>(ent, jj + lb, mw, nm, prefetch); } break;
 #define DVBS2_V2_SWITCH switch (deg) { \
         DVBS2_V2_CASE(3) DVBS2_V2_CASE(4) DVBS2_V2_CASE(5) DVBS2_V2_CASE(6) DVBS2_V2_CASE(7) DVBS2_V2_CASE(8) \
         DVBS2_V2_CASE(9) DVBS2_V2_CASE(10) DVBS2_V2_CASE(11) DVBS2_V2_CASE(12) DVBS2_V2_CASE(13) DVBS2_V2_CASE(14) \
@@ -1451,7 +1465,7 @@ __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, con
         DVBS2_V2_CASE(27) DVBS2_V2_CASE(28) DVBS2_V2_CASE(29) DVBS2_V2_CASE(30) DVBS2_V2_CASE(31) DVBS2_V2_CASE(32) \
         default: break; }
 
-#define DVBS2_CHAIN_CASE(D) case D: if constexpr (D >= 4 && D <= DMAX && D > DMAX - 8) { check_node_chain_v2<(D >= 4 ? D : 4), DMAX, P6>(ent, jj, jj + lb, work, block, mw, nm, htab16, hb_ctr, hb_epoch, hb_lane); } break;
+#define DVBS2_CHAIN_CASE(D) case D: if constexpr (D >= 4 && D <= DMAX && D > DMAX - 8) { check_node_chain_v2<(D >= 4 ? D : 4), DMAX, P6, TC>(ent, jj, jj + lb, work, block, mw, nm, htab16, hb_ctr, hb_epoch, hb_lane); } break;
 #define DVBS2_CHAIN_SWITCH switch (deg) { \
         DVBS2_CHAIN_CASE(4) DVBS2_CHAIN_CASE(5) DVBS2_CHAIN_CASE(6) DVBS2_CHAIN_CASE(7) DVBS2_CHAIN_CASE(8) \
         DVBS2_CHAIN_CASE(9) DVBS2_CHAIN_CASE(10) DVBS2_CHAIN_CASE(11) DVBS2_CHAIN_CASE(12) DVBS2_CHAIN_CASE(13) DVBS2_CHAIN_CASE(14) \
@@ -1465,7 +1479,7 @@ __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, con
 // state made the compiler spill the regular entries of EVERY four- and eight-entry layer around it, 9/10 normal's multi-pair
 // layers went from 12-17 k to 25-34 k cycles.)
 #define DVBS2_HAZ_CALL1(D, NCV, LRV, TLCV) { \
-        if (layer0) check_node_hazard<D, NCV, true, false, false, HZ2, LRV, TLCV, (MINW == 1), (DMAX <= 8)>(lds_all, ent, jj, lb, work, block, block2, mw, nm, 0, nullptr, htab, hb_ctr, hb_epoch, hb_lane, hz_ph); else { if constexpr (!kPure) check_node_hazard<D, NCV, false, false, false, HZ2, LRV, TLCV, (MINW == 1), (DMAX <= 8)>(lds_all, ent, jj, lb, work, block, block2, mw, nm, 0, nullptr, htab, hb_ctr, hb_epoch, hb_lane, hz_ph); } }
+        if (layer0) check_node_hazard<D, NCV, true, false, false, HZ2, LRV, TLCV, (MINW == 1), (DMAX <= 8), false, 0, false, TC>(lds_all, ent, jj, lb, work, block, block2, mw, nm, 0, nullptr, htab, hb_ctr, hb_epoch, hb_lane, hz_ph); else { if constexpr (!kPure) check_node_hazard<D, NCV, false, false, false, HZ2, LRV, TLCV, (MINW == 1), (DMAX <= 8), false, 0, false, TC>(lds_all, ent, jj, lb, work, block, block2, mw, nm, 0, nullptr, htab, hb_ctr, hb_epoch, hb_lane, hz_ph); } }
 #define DVBS2_HAZ_CALL(D, NCV) { if constexpr (D - 2 >= NCV) { \
         if constexpr (kTlc<DMAX, HZ2> && (!SOFT || DVBS2_TLC_SOFT) && MINW == 1 && (NCV == 4 || NCV == 8)) { if (block2 > 0 && htab != nullptr) DVBS2_HAZ_CALL1(D, NCV, (DMAX >= kTlcLowRegMinDmax), true) else DVBS2_HAZ_CALL1(D, NCV, (kLowReg<DMAX, HZ2>), false) } \
         else DVBS2_HAZ_CALL1(D, NCV, (kLowReg<DMAX, HZ2>), false) } }
@@ -1473,7 +1487,7 @@ __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, con
         if (nc == 2) DVBS2_HAZ_CALL((D >= 4 ? D : 4), 2) else if (nc == 4) DVBS2_HAZ_CALL((D >= 4 ? D : 4), 4) else { if constexpr (HZ2 && DMAX <= kMaxHazard12Dmax) { if (nc == 8) DVBS2_HAZ_CALL((D >= 4 ? D : 4), 8) else DVBS2_HAZ_CALL((D >= 4 ? D : 4), 12) } else DVBS2_HAZ_CALL((D >= 4 ? D : 4), 8) } } break;
 // The same with the packed first / last phase (check_node_hazard<..., V2P>): regular layers i > 0 of the builds with packed nodes whose
 // wave record the host laid out in the packed format (header bit 14); the ordered phase is the plain one, instantiation for instantiation.
-#define DVBS2_HAZP_CALL1(D, NCV, TLCV) { check_node_hazard<D, NCV, false, false, false, HZ2, false, TLCV, (MINW == 1), (DMAX <= 8), true, DMAX, P6>(lds_all, ent, jj, lb, work, block, block2, mw, nm, 0, nullptr, htab, hb_ctr, hb_epoch, hb_lane, hz_ph); }
+#define DVBS2_HAZP_CALL1(D, NCV, TLCV) { check_node_hazard<D, NCV, false, false, false, HZ2, false, TLCV, (MINW == 1), (DMAX <= 8), true, DMAX, P6, TC>(lds_all, ent, jj, lb, work, block, block2, mw, nm, 0, nullptr, htab, hb_ctr, hb_epoch, hb_lane, hz_ph); }
 #define DVBS2_HAZP_CALL(D, NCV) { if constexpr (D - 2 >= NCV) { \
         if constexpr (kTlc<DMAX, HZ2> && (!SOFT || DVBS2_TLC_SOFT) && MINW == 1 && (NCV == 4 || NCV == 8)) { if (block2 > 0 && htab != nullptr) DVBS2_HAZP_CALL1(D, NCV, true) else DVBS2_HAZP_CALL1(D, NCV, false) } \
         else DVBS2_HAZP_CALL1(D, NCV, false) } }
@@ -1508,17 +1522,18 @@ __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, con
 // Step 1 of the full syndrome test (see the kernel): the 360-bit sign vectors of all N / 360 groups, one thread per eight consecutive
 // LLR bytes; returns non-zero when one of this thread's bytes is a zero LLR. A function of its own, NOT inlined: inlined, its loop
 // perturbed the register allocation of the sweep and cost the never-converging batches -- where it never runs -- up to 4 % (S2X 154/180).
-__device__ __attribute__((noinline)) int syndrome_sign_vectors(const lds_byte_t* lds, lds_u32_t* sv, int N, int tid)
+__device__ __attribute__((noinline)) int syndrome_sign_vectors(const lds_byte_t* lds, lds_u32_t* sv, int N, int tid, bool tc /*LLR bytes are two's complement*/)
 {
     lds_byte_t* svb = reinterpret_cast<lds_byte_t*>(sv);
     int zero = 0;
 #pragma unroll 2
     for (int blk = tid; blk < N / 8; blk += kHalf) {
         const v2u32 v = *reinterpret_cast<const lds_v2u_t*>(lds + 8 * blk);
-        const uint32_t xa = v.x ^ 0x80808080u, xb = v.y ^ 0x80808080u; // two's complement: zero bytes = zero LLRs
+        const uint32_t ob = tc ? 0u : 0x80808080u;
+        const uint32_t xa = v.x ^ ob, xb = v.y ^ ob; // two's complement: zero bytes = zero LLRs
         zero |= (int)((((xa - 0x01010101u) & ~xa) | ((xb - 0x01010101u) & ~xb)) & 0x80808080u);
         // sign bit of byte i -> bit i (offset binary: negative <=> bit 7 clear): bits 0, 8, 16, 24 gathered by a multiply
-        const uint32_t na = (((~v.x & 0x80808080u) >> 7) * 0x01020408u) >> 24, nb = (((~v.y & 0x80808080u) >> 7) * 0x01020408u) >> 24;
+        const uint32_t na = (((xa & 0x80808080u) >> 7) * 0x01020408u) >> 24, nb = (((xb & 0x80808080u) >> 7) * 0x01020408u) >> 24;
         const int g = blk / 45;
         svb[g * (kSvWords * 4) + (blk - 45 * g)] = (uint8_t)((na & 0xfu) | ((nb & 0xfu) << 4));
     }
@@ -1568,6 +1583,8 @@ __global__ __launch_bounds__(SOLO ? kSoloThreads : kThreads, SOLO ? 4 : MINW) vo
     // nodes of the degree class 32 cost the packed ones around them 5 % through register allocation --; the host runs such a build only
     // for tables whose every (layer > 0, wave) record fits the packed format (ldpc_hip.hip)
     constexpr bool kPure = V2 && !SOFT && v2_pure_class(DMAX);
+    constexpr bool TC = V2 && DMAX <= DVBS2_TC_MAX_DMAX;        // LLR bytes in LDS as two's complement (see lds_rdx)
+    constexpr uint32_t kObState = TC ? 0x80808080u : 0u;        // LDS bytes <-> the offset-binary state in HBM
     int solo_tid = (int)threadIdx.x;
     int solo_slot = -1, solo_pat = 0;
     if constexpr (SOLO) {
@@ -1630,7 +1647,7 @@ __global__ __launch_bounds__(SOLO ? kSoloThreads : kThreads, SOLO ? 4 : MINW) vo
             auto put = [&](int n, int8_t v) {
                 int idx = n;
                 if (n >= K) { const int r = n - K, jq = r / q; idx = K + kM * (r - jq * q) + jq; } // pty[360*i + j] = parity[q*j + i]
-                lds[idx] = (uint8_t)v ^ 0x80u;
+                lds[idx] = (uint8_t)v ^ (TC ? 0x00u : 0x80u);
             };
             const float N0 = dm.n0[dm.n0_count > 1 ? f : 0];
             const float2* src = reinterpret_cast<const float2*>(dm.syms) + (size_t)f * dm.n_syms;
@@ -1653,7 +1670,7 @@ __global__ __launch_bounds__(SOLO ? kSoloThreads : kThreads, SOLO ? 4 : MINW) vo
             const uint2* src = reinterpret_cast<const uint2*>(llr_in + (size_t)f * N);
             for (int c = tid; c < N / 8; c += kHalf) {
                 uint2 v = src[c];
-                v.x ^= 0x80808080u; v.y ^= 0x80808080u;
+                if constexpr (!TC) { v.x ^= 0x80808080u; v.y ^= 0x80808080u; }
                 const int n = 8 * c;
                 if (n < K) *reinterpret_cast<lds_v2u_t*>(lds + n) = (v2u32){ v.x, v.y }; // K % 8 == 0
                 else {
@@ -1672,7 +1689,7 @@ __global__ __launch_bounds__(SOLO ? kSoloThreads : kThreads, SOLO ? 4 : MINW) vo
             if (it >= tgt) finished = true; // nothing to do for this frame in this pass
             else {
                 const uint2* src = reinterpret_cast<const uint2*>(state + (size_t)f * N);
-                for (int c = tid; c < N / 8; c += kHalf) { const uint2 v = src[c]; *reinterpret_cast<lds_v2u_t*>(lds + 8 * c) = (v2u32){ v.x, v.y }; }
+                for (int c = tid; c < N / 8; c += kHalf) { const uint2 v = src[c]; *reinterpret_cast<lds_v2u_t*>(lds + 8 * c) = (v2u32){ v.x ^ kObState, v.y ^ kObState }; } // (the state in HBM is offset binary in every build)
             }
         }
     }
@@ -1771,7 +1788,7 @@ __global__ __launch_bounds__(SOLO ? kSoloThreads : kThreads, SOLO ? 4 : MINW) vo
             uint32_t x = 0, z = 0;
             for (int k = 0; k < deg; k++) {
                 const int a0 = tid + (int)rec[4 + 2 * k] - ((uint32_t)tid < rec[5 + 2 * k] ? 0 : kM);
-                uint32_t v = lds[a0];
+                uint32_t v = (uint32_t)lds[a0] ^ (TC ? 0x80u : 0x00u); // offset-binary value
                 if (i0 == 0 && k == deg - 1 && tid == 0) v = 0x81u; // check (0,0) has no previous parity: neutral +1
                 x ^= v;
                 z |= (v == 0x80u);
@@ -1792,7 +1809,7 @@ __global__ __launch_bounds__(SOLO ? kSoloThreads : kThreads, SOLO ? 4 : MINW) vo
             // thread and group -- a fifth of the LDS instructions; at the operating point, where nearly every test is a full one,
             // the tests were a tenth of the decode (cycle stamps).
             {
-                const int zero = syndrome_sign_vectors(lds, sv, N, tid);
+                const int zero = syndrome_sign_vectors(lds, sv, N, tid, TC);
                 if (__ballot(zero != 0) != 0 && lane == 0) flags[0] = 1;
             }
         }
@@ -2023,7 +2040,7 @@ __global__ __launch_bounds__(SOLO ? kSoloThreads : kThreads, SOLO ? 4 : MINW) vo
     if (have_frame && !untouched) {
         if (tid == 0) { iters[f] = it; good[f] = is_good ? 1 : 0; }
         uint2* dst = reinterpret_cast<uint2*>(state + (size_t)f * N);
-        for (int c = tid; c < N / 8; c += kHalf) { const v2u32 v = *reinterpret_cast<const lds_v2u_t*>(lds + 8 * c); dst[c] = make_uint2(v.x, v.y); }
+        for (int c = tid; c < N / 8; c += kHalf) { const v2u32 v = *reinterpret_cast<const lds_v2u_t*>(lds + 8 * c); dst[c] = make_uint2(v.x ^ kObState, v.y ^ kObState); }
     }
     if constexpr (SOLO) { // give the CU's pattern slot back
         if (tid == 0) __hip_atomic_fetch_add(cu_slots + solo_slot, solo_pat ? -0x10000 : -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -3,8 +3,8 @@
 
 HBM bytes per launch of every BASELINE configuration's dominant kernel from the rocprofv3 PMC passes of ONE bench.py run
 (`python bench.py --steps 3 --warmup 1 --no-cpu-baseline --gate none --only config3,config4,config5,config5_s2x`; FETCH_SIZE and
-WRITE_SIZE in separate passes). Per kernel the counters are sums over all its dispatches in the run = a known number of frames
-(warm-up + timed steps, no parity-gate launches); scaled to one launch of the configuration's batch. The file records the digest of
+WRITE_SIZE in separate passes). Per kernel the counters are sums over all its dispatches in the run, every one a whole batch
+(warm-up + timed steps, no parity-gate launches); divided by the pass's own dispatch count = one launch of the configuration's batch. The file records the digest of
 gr-dvbs2rx_amd/csrc it was profiled at (bench.csrc_sha256); bench.py reports `traffic` only for exactly that tree. Units KiB; FETCH_SIZE doubled (MI355X_MICROARCH.md: gfx950 tallies 128-byte read requests at
 64 B; calibrated in round 1 against this kernel family's known message byte count). Each entry also carries the SQ pass of the same run
 (`sq`: instruction / activity / wait counters summed over the kernel's dispatches + their total duration), from which bench.py computes
@@ -59,7 +59,10 @@ for name, (kern, frames, trials, total) in runs.items():
     if kern not in fetch or kern not in write:
         print("no counters for", name, kern); continue
     fs, ws = fetch[kern]["FETCH_SIZE"], write[kern]["WRITE_SIZE"]
-    per_launch = (2 * fs + ws) * 1024 * frames // total
+    # per launch = sum / dispatches of the pass (every dispatch of the run decodes one whole batch: --gate none, no 32-frame gate launches; the
+    # number of warm-up calls is time-based since round 5, so the counters' own dispatch counts are what is divided by)
+    per_launch = int((2 * fs / fetch[kern]["_dispatches"] + ws / write[kern]["_dispatches"]) * 1024)
+    total = frames * fetch[kern]["_dispatches"]
     entries.append({"config": name, "kernel": kern, "frames_per_launch": frames, "max_trials": trials, "fetch_size_kb_raw_sum": fs,
                     "write_size_kb_sum": ws, "frames_in_sum": total, "hbm_bytes_per_launch": per_launch, "source": "profiles/" + os.path.basename(src)})
     if kern in sqp:  # the SQ pass of the same run (sums over its dispatches): bench.py derives `roofline.limiter` from it
