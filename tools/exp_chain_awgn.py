@@ -28,3 +28,13 @@ for prof in (False, True, False):
         torch.cuda.synchronize(); t = time.perf_counter(); fn(); torch.cuda.synchronize(); ts.append((time.perf_counter() - t) * 1e3)
     print("profiling", prof, " ms per call:", " ".join(f"{x:.2f}" for x in ts))
     if prof: print("  ldpc launch ms", ch.profile(False))
+# after seconds of GPU idleness (what a parity gate on the host cores leaves behind): per-call times again, and with all host cores busy meanwhile
+import subprocess
+for label, busy in (("idle 6 s", False), ("idle 6 s, then host cores busy during the calls", True)):
+    time.sleep(6.0)
+    ps = [subprocess.Popen([sys.executable, "-c", "import time\nt=time.time()\nwhile time.time()-t<4: pass"]) for _ in range(os.cpu_count() if busy else 0)]
+    ts = []
+    for _ in range(40):
+        torch.cuda.synchronize(); t = time.perf_counter(); fn(); torch.cuda.synchronize(); ts.append((time.perf_counter() - t) * 1e3)
+    for p in ps: p.wait()
+    print(label, " ms per call:", " ".join(f"{x:.2f}" for x in ts))
