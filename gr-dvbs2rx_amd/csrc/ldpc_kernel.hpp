@@ -1798,7 +1798,11 @@ __global__ __launch_bounds__(SOLO ? kSoloThreads : kThreads, SOLO ? 4 : MINW) vo
             if (__ballot(bad_pre) != 0 && lane == 0) flags[2] = 1;
         }
         lds_barrier();
+#ifdef DVBS2_EXP_ALWAYS_FULL // timing experiment (same results): the full test after every update, whatever the pre-test says
+        const bool need_full = need_synd;
+#else
         const bool need_full = need_synd && flags[2] == 0;
+#endif
         if (tid == 0) flags[3] = need_full ? 1 : 0;
         lds_barrier();
         const bool full_any = flags[3] != 0 || (!soft_bar && !SOLO && other_flags[3] != 0); // uniform over the barrier domain

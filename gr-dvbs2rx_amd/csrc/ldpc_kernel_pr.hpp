@@ -28,7 +28,7 @@
 namespace dvbs2 {
 
 __host__ __device__ constexpr size_t pr_half_bytes(int K) { return ((size_t)K + kM + 15) / 16 * 16; }
-__host__ __device__ constexpr size_t pr_lds_bytes(int N, int K) { return 2 * pr_half_bytes(K) + (size_t)(N / kM) * kSvWords * 4 + 64; }
+__host__ __device__ constexpr size_t pr_lds_bytes(int N, int K) { return 2 * pr_half_bytes(K) + 2 * (size_t)(N / kM) * kSvWords * 4 + 64; } // two frames + one sign-vector area EACH (round 5)
 
 #ifdef DVBS2_LDPC_INSTANTIATE_PR
 #define DVBS2_PR_CASE(D) case D: { \
@@ -116,6 +116,41 @@ __device__ __forceinline__ uint32_t check_node_pr6(uint8_t* __restrict__ lds, co
     return y | ((uint32_t)spare << 24);
 }
 
+// Step 1 of the full syndrome test of the parity-in-records kernel: sign bits / zero test of all N LLRs of one frame, 360 per group, into the
+// frame's sign-vector area. A function of its own, NOT inlined: the full test runs rarely on never-converging input, and inlined its chunk of
+// loads cost the sweep of every table 1-3 % through register allocation (round 5; the same rule as syndrome_sign_vectors in ldpc_kernel.hpp).
+template <bool W1>
+__device__ __attribute__((noinline)) unsigned long long pr_sign_vectors(const lds_byte_t* lds, lds_u32_t* sv, const uint32_t* __restrict__ msg_base,
+                                                                        int K, int N, int q, int tid)
+{
+    constexpr int RW = W1 ? 1 : 2, PW = RW - 1;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int NGD = K / kM, NG = N / kM;
+    const bool active = tid < kM;
+    unsigned long long zero_any = 0;
+    auto put_row = [&](int g, uint32_t v) { // sign bits / zero test of the 360 LLRs of group g, one per lane
+        const unsigned long long neg = __ballot(v < 0x80u);
+        zero_any |= __ballot(v == 0x80u);
+        if (lane == 0) *reinterpret_cast<lds_v2u_t*>(&sv[g * kSvWords + 2 * wave]) = (v2u32){ (uint32_t)neg, (uint32_t)(neg >> 32) };
+    };
+    for (int g = 0; g < NGD; g++) put_row(g, active ? (uint32_t)lds[kM * g + tid] : 0xffu); // information part: LDS
+    put_row(NG - 1, active ? (uint32_t)lds[K + tid] : 0xffu);                              // parity row q - 1: LDS
+    // Parity rows 0 .. q-2 live in the message records in HBM (byte 3 of word PW of layer r + 1). Round 5: kSynChunk of them are
+    // requested at once, unconditionally (every thread of the half has a slot in a record word) -- one load per row inside the
+    // per-row branch was one round trip to memory per row, 8.6 us of a 15.7 us full test of short 1/4.
+    constexpr int kSynChunk = 16;
+    for (int r0 = 0; r0 < q - 1; r0 += kSynChunk) {
+        uint32_t w[kSynChunk];
+#pragma unroll
+        for (int c = 0; c < kSynChunk; c++) {
+            w[c] = msg_base[((min(r0 + c, q - 2) + 1) * RW + PW) * kMsgStride + tid];
+        }
+#pragma unroll
+        for (int c = 0; c < kSynChunk; c++) if (r0 + c < q - 1) put_row(NGD + r0 + c, active ? w[c] >> 24 : 0xffu);
+    }
+    return zero_any;
+}
+
 // Records use the PR LDS layout: data entries as in the classic kernel; own parity of the last layer at K + j;
 // previous parity of layer 0 at K + (j + 359) mod 360 (S0 = K + 359, thr = 1).
 template <bool W1>
@@ -138,13 +173,18 @@ __global__ __launch_bounds__(kThreads, 6) void ldpc_layered_pr_kernel(
     const int lb_rel = half * (int)pr_half_bytes(K);
     const int lb = lb_rel + lds_address_of(lds_all); // absolute LDS address of this frame's region
     lds_byte_t* lds = (lds_byte_t*)lds_all + lb_rel; // (address-space-3 typed pointers: ldpc_kernel.hpp, lds_byte_t)
-    lds_u32_t* sv = reinterpret_cast<lds_u32_t*>((lds_byte_t*)lds_all + 2 * (int)pr_half_bytes(K));
-    volatile lds_i32_t* flags_all = reinterpret_cast<volatile lds_i32_t*>(sv + (N / kM) * kSvWords);
+    // Round 5: a sign-vector area per FRAME. With one area per workgroup the two frames took turns through the full syndrome test (three
+    // barriers each), and a full test cost both of them 27 us -- three quarters of an update sweep of short 1/4 (measured with a build that
+    // runs it after every update): at the operating point, where converged frames pass the pre-test until their group stops, that was a
+    // third of the decode (config4_awgn at 0.65 of the proportional rate).
+    lds_u32_t* sv_base = reinterpret_cast<lds_u32_t*>((lds_byte_t*)lds_all + 2 * (int)pr_half_bytes(K));
+    lds_u32_t* sv = sv_base + half * (N / kM) * kSvWords;
+    volatile lds_i32_t* flags_all = reinterpret_cast<volatile lds_i32_t*>(sv_base + 2 * (N / kM) * kSvWords);
     volatile lds_i32_t* flags = flags_all + 8 * half;        // [0] bad-or, [1] finished, [2] pre-test failed, [3] full test needed
     volatile lds_i32_t* other_flags = flags_all + 8 * (1 - half);
     const int f = 2 * blockIdx.x + half;
     const bool have_frame = f < n_frames;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63;
     const int NGD = K / kM, NG = N / kM;
     const bool active = tid < kM;
     const int row = tid < kM ? tid : kM - 1; // threads 360..383 mirror row 359 (ldpc_kernel.hpp)
@@ -222,26 +262,18 @@ __global__ __launch_bounds__(kThreads, 6) void ldpc_layered_pr_kernel(
             if (__ballot(bad_pre) != 0 && lane == 0) flags[2] = 1;
         }
         __syncthreads();
+#ifdef DVBS2_EXP_ALWAYS_FULL // timing experiment (same results): the full test after every update, whatever the pre-test says
+        const bool need_full = need_synd;
+#else
         const bool need_full = need_synd && flags[2] == 0;
+#endif
         if (tid == 0) flags[3] = need_full ? 1 : 0;
         __syncthreads();
         if (flags[3] != 0 || other_flags[3] != 0) { // uniform over the workgroup
-            // the sign-vector buffer is shared: the halves take turns
-            for (int h = 0; h < 2; h++) {
-                const bool mine = need_full && half == h;
+            { // (both frames at once: each has its own sign-vector area)
+                const bool mine = need_full;
                 if (mine) {
-                    unsigned long long zero_any = 0;
-                    for (int g = 0; g < NG; g++) {
-                        uint32_t v = 0xffu;
-                        if (active) {
-                            if (g < NGD) v = lds[kM * g + tid];
-                            else if (g == NG - 1) v = lds[K + tid];
-                            else v = msg_base[((g - NGD + 1) * RW + PW) * kMsgStride + tid] >> 24; // parity row g - NGD
-                        }
-                        const unsigned long long neg = __ballot(v < 0x80u);
-                        zero_any |= __ballot(v == 0x80u);
-                        if (lane == 0) *reinterpret_cast<lds_v2u_t*>(&sv[g * kSvWords + 2 * wave]) = (v2u32){ (uint32_t)neg, (uint32_t)(neg >> 32) };
-                    }
+                    const unsigned long long zero_any = pr_sign_vectors<W1>(lds, sv, msg_base, K, N, q, tid);
                     if (zero_any != 0 && lane == 0) flags[0] = 1;
                 }
                 __syncthreads();
