@@ -562,7 +562,7 @@ __device__ __forceinline__ void check_node_v2(const uint32_t* ent /*record words
     // (Issuing the NEXT layer's scalar record loads from this point -- scalar memory shares its counter with LDS, so a load in
     // flight turns every LDS wait into "wait for everything" -- was tried with a scheduling barrier and an ordering dependency:
     // it cost 9 % on table B4 and a factor 4 on the degree-30 class through what it does to register allocation. The loads stay
-    // at the top of the layer)
+    // at the top of the layer; notes/history.md 3.4.)
     (void)prefetch_next_record;
     int mg[DEG];
 #pragma unroll
