@@ -46,6 +46,7 @@ private:
     uint16_t* d_antilog_ = nullptr;
     uint16_t* d_log_ = nullptr;
     uint16_t* d_quad_ = nullptr;
+    uint16_t* d_hcol_ = nullptr;  // parity-check columns for the syndrome stage (32 B per codeword bit)
     uint8_t* d_scramble_ = nullptr;
     bool descramble_ = false;
     int n_cus_ = 0;

@@ -98,6 +98,7 @@ private:
     int* d_target_ = nullptr;     // per frame: updates to reach in a resume pass
     int* d_gsync_ = nullptr;      // one status word per frame: group-synchronous stop inside the first pass (ldpc_kernel.hpp, group_decide)
     bool gsync_on_ = false;
+    bool pr_shared_sv_ = false;   // parity-in-records kernel: one sign-vector area per workgroup (two do not fit twice into a CU's LDS)
     int* d_flag_ = nullptr;       // [slot] = number of unresolved groups
     int* h_flag_ = nullptr;       // pinned, [slot]
     struct Pending { bool active = false; int n_frames = 0, max_trials = 0, out_mode = 0, frame_base = 0;

@@ -112,7 +112,8 @@ LdpcDecoderHip::LdpcDecoderHip(const LdpcTableDesc* table, int out_bits_message,
     if (const char* e = getenv("DVBS2_PR")) pr_ = degmax <= 7 && atoi(e) != 0;
     for (const LdpcLayer& L : sched_.layers)
         if (L.block < 360 && (L.n_conflict > 4 || (L.n_conflict > 2 ? 4 : 2) > L.cnt)) pr_ = false;
-    if (2 * pr_lds_bytes(sched_.N, sched_.K) > 160 * 1024) pr_ = false;
+    pr_shared_sv_ = 2 * pr_lds_bytes(sched_.N, sched_.K) > 160 * 1024; // (normal frames forced onto this kernel: one sign-vector area per workgroup)
+    if (2 * pr_lds_bytes(sched_.N, sched_.K, pr_shared_sv_) > 160 * 1024) pr_ = false;
     // degree class: the sweep kernel is built per multiple of four (message dwords per check); degree <= 4 tables that do not run the
     // parity-in-records kernel (1/4 normal, S2X 2/9 normal) get the one-dword class -- they move ~4.4 TB/s with two (+8 %)
     dmax_ = pr_ ? 8 : std::max(4, (degmax + 3) / 4 * 4);
@@ -438,7 +439,7 @@ LdpcDecoderHip::LdpcDecoderHip(const LdpcTableDesc* table, int out_bits_message,
         d_cu_slots_ = slots;
     }
     kname_ = pr_ ? std::string(pr_w1_ ? "ldpc_layered_pr_kernel<w1>" : "ldpc_layered_pr_kernel") : "ldpc_layered_kernel<" + std::to_string(dmax_) + (dense_ ? ", dense>" : std::string(v2_ ? ", packed" : chain_plain_ ? ", chain" : "") + (solo_ ? ", solo>" : hz2_ ? ", hz2>" : soft_bar_ ? ", soft>" : ">"));
-    lds_bytes_ = pr_ ? pr_lds_bytes(sched_.N, sched_.K) : 2 * half_lds_bytes(sched_.N);
+    lds_bytes_ = pr_ ? pr_lds_bytes(sched_.N, sched_.K, pr_shared_sv_) : 2 * half_lds_bytes(sched_.N);
     if (const char* e = getenv("DVBS2_LDS_PAD")) lds_bytes_ += (size_t)atoi(e); // occupancy experiments only
     if (pr_) HIP_OK(ldpc_pr_prepare(lds_bytes_));
     else switch (dmax_) {
@@ -470,7 +471,7 @@ void LdpcDecoderHip::launch_sweep(const int8_t* in, bool resume, int stop_on_goo
     la.iters = d_iters_ + fb; la.good = d_good_ + fb; la.target = resume ? d_target_ + fb : nullptr;
     const bool gs = gsync_on_ && !resume && stop_on_good; // group-synchronous stop: bit 2 of the flag word; its words start from zero
     if (gs) (void)hipMemsetAsync(d_gsync_ + frame_base, 0, (size_t)n_frames * 4, stream); // (frame_base is a multiple of the group size: enqueue())
-    la.n_frames = n_frames; la.N = sched_.N; la.K = sched_.K; la.q = sched_.q; la.cap = max_trials; la.stop_on_good = stop_on_good | (soft_bar_ ? 2 : 0) | (gs ? 4 : 0);
+    la.n_frames = n_frames; la.N = sched_.N; la.K = sched_.K; la.q = sched_.q; la.cap = max_trials; la.stop_on_good = stop_on_good | (soft_bar_ ? 2 : 0) | (gs ? 4 : 0) | (pr_ && pr_shared_sv_ ? 8 : 0);
     la.tdbg = d_tdbg_; la.lds_bytes = solo_ ? half_lds_bytes(sched_.N) : lds_bytes_; la.stream = stream; la.dense = dense_;
     la.v2 = pr_ ? pr_w1_ : v2_; la.solo = solo_; la.chain = chain_plain_; la.hz2 = hz2_; la.soft = soft_bar_; la.cu_slots = d_cu_slots_;
     la.dm = DemapFused{};

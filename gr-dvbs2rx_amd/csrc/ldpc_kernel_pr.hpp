@@ -28,7 +28,9 @@
 namespace dvbs2 {
 
 __host__ __device__ constexpr size_t pr_half_bytes(int K) { return ((size_t)K + kM + 15) / 16 * 16; }
-__host__ __device__ constexpr size_t pr_lds_bytes(int N, int K) { return 2 * pr_half_bytes(K) + 2 * (size_t)(N / kM) * kSvWords * 4 + 64; } // two frames + one sign-vector area EACH (round 5)
+// two frames + sign-vector areas: one PER FRAME (round 5: the frames run their full syndrome tests at the same time), or ONE shared by the
+// workgroup where two do not fit twice into the 160 KB of a CU (normal frames forced onto this kernel: the frames then take turns; bit 3 of the flag word)
+__host__ __device__ constexpr size_t pr_lds_bytes(int N, int K, bool shared_sv = false) { return 2 * pr_half_bytes(K) + (shared_sv ? 1 : 2) * (size_t)(N / kM) * kSvWords * 4 + 64; }
 
 #ifdef DVBS2_LDPC_INSTANTIATE_PR
 #define DVBS2_PR_CASE(D) case D: { \
@@ -157,7 +159,7 @@ template <bool W1>
 __global__ __launch_bounds__(kThreads, 6) void ldpc_layered_pr_kernel(
     const uint32_t* __restrict__ recs, const int8_t* __restrict__ llr_in, uint8_t* __restrict__ state,
     uint32_t* __restrict__ msgs, int* __restrict__ iters, int* __restrict__ good, const int* __restrict__ target,
-    int n_frames, int N, int K, int q, int cap, int stop_on_good /*bit 0: stop at a good syndrome, bit 2: group-synchronous stop (ldpc_kernel.hpp, group_decide)*/)
+    int n_frames, int N, int K, int q, int cap, int stop_on_good /*bit 0: stop at a good syndrome, bit 2: group-synchronous stop (ldpc_kernel.hpp, group_decide), bit 3: one sign-vector area per workgroup*/)
 {
     if (!llr_in) { // resume launch: a workgroup whose frames are both at their target leaves before touching LDS
         const int fa = 2 * (int)blockIdx.x, fb = fa + 1;
@@ -178,8 +180,9 @@ __global__ __launch_bounds__(kThreads, 6) void ldpc_layered_pr_kernel(
     // runs it after every update): at the operating point, where converged frames pass the pre-test until their group stops, that was a
     // third of the decode (config4_awgn at 0.65 of the proportional rate).
     lds_u32_t* sv_base = reinterpret_cast<lds_u32_t*>((lds_byte_t*)lds_all + 2 * (int)pr_half_bytes(K));
-    lds_u32_t* sv = sv_base + half * (N / kM) * kSvWords;
-    volatile lds_i32_t* flags_all = reinterpret_cast<volatile lds_i32_t*>(sv_base + 2 * (N / kM) * kSvWords);
+    const bool sv_shared = (stop_on_good & 8) != 0; // uniform: one area for the workgroup (see pr_lds_bytes)
+    lds_u32_t* sv = sv_base + (sv_shared ? 0 : half) * (N / kM) * kSvWords;
+    volatile lds_i32_t* flags_all = reinterpret_cast<volatile lds_i32_t*>(sv_base + (sv_shared ? 1 : 2) * (N / kM) * kSvWords);
     volatile lds_i32_t* flags = flags_all + 8 * half;        // [0] bad-or, [1] finished, [2] pre-test failed, [3] full test needed
     volatile lds_i32_t* other_flags = flags_all + 8 * (1 - half);
     const int f = 2 * blockIdx.x + half;
@@ -270,8 +273,8 @@ __global__ __launch_bounds__(kThreads, 6) void ldpc_layered_pr_kernel(
         if (tid == 0) flags[3] = need_full ? 1 : 0;
         __syncthreads();
         if (flags[3] != 0 || other_flags[3] != 0) { // uniform over the workgroup
-            { // (both frames at once: each has its own sign-vector area)
-                const bool mine = need_full;
+            for (int h = 0; h < (sv_shared ? 2 : 1); h++) { // both frames at once when each has its own sign-vector area, else in turns
+                const bool mine = need_full && (!sv_shared || half == h);
                 if (mine) {
                     const unsigned long long zero_any = pr_sign_vectors<W1>(lds, sv, msg_base, K, N, q, tid);
                     if (zero_any != 0 && lane == 0) flags[0] = 1;
