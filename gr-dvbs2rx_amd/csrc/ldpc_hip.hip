@@ -99,6 +99,8 @@ LdpcDecoderHip::LdpcDecoderHip(const LdpcTableDesc* table, int out_bits_message,
         for (LdpcLayer& L : sched_.layers) { L.block = 360; L.n_conflict = 0; }
         sched_.conflict_layers = 0;
     }
+    if (getenv("DVBS2_EXP_NOSYNC")) // timing-only bound (wrong results): no barrier in front of a regular layer
+        for (LdpcLayer& L : sched_.layers) if (L.block >= 360) L.sync_before = 0;
     int degmax = 0, degmin = 1000;
     for (const LdpcLayer& L : sched_.layers) { degmax = std::max(degmax, L.cnt + 2); degmin = std::min(degmin, L.cnt + 2); }
     if (degmax > 32) { err_ = "check degree > 32 unsupported"; return; }
