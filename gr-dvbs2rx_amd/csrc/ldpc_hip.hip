@@ -290,7 +290,7 @@ LdpcDecoderHip::LdpcDecoderHip(const LdpcTableDesc* table, int out_bits_message,
     // "Pure" packed builds (ldpc_kernel.hpp, kPure: the hardware-barrier packed build of the degree class 32): the plain nodes exist for layer 0
     // only, so EVERY (layer > 0, wave) record has to fit the packed format -- mixed entries within the fix slots, no one-wave walk layer. A
     // table that does not fit takes the plain build (of the 57 tables this concerns 9/10 normal only, which fits).
-    if (v2 && !soft_bar_ && v2_pure_class(dmax_)) {
+    if (v2 && (!soft_bar_ || DVBS2_V2_PURE_SOFT) && v2_pure_class(dmax_)) {
         bool fits = v2p_on;
         for (int i = 1; fits && i < sched_.q; i++) {
             const LdpcLayer& L = sched_.layers[i];
@@ -300,7 +300,7 @@ LdpcDecoderHip::LdpcDecoderHip(const LdpcTableDesc* table, int out_bits_message,
                 const int lo = 64 * w, hi = std::min(64 * w + 63, 359);
                 int nm = 0;
                 for (int k = L.block < 360 ? ncv : 0; k < L.cnt; k++) { const int thr = 360 - (int)sched_.entries[L.entry_off + layer_order[i][k]].rot; nm += lo < thr && thr <= hi; }
-                if (nm > (L.block < 360 ? std::min(dmax_ / 2, (int)L.cnt) - ncv : std::min(dmax_ / 4, (int)L.cnt))) fits = false;
+                if (nm > (L.block < 360 ? std::min(dmax_ / 2, (int)L.cnt) - ncv : std::min(v2_nfix(dmax_), (int)L.cnt))) fits = false;
             }
         }
         if (!fits) v2 = false;
@@ -328,7 +328,7 @@ LdpcDecoderHip::LdpcDecoderHip(const LdpcTableDesc* table, int out_bits_message,
             const int lo = 64 * w, hi = std::min(64 * w + 63, 359);
             int nm = 0;
             for (int k = 2; k < L.cnt; k++) { const int thr = 360 - (int)sched_.entries[L.entry_off + k].rot; nm += lo < thr && thr <= hi; }
-            if (nm > dmax_ / 4) fits = false;
+            if (nm > v2_nfix(dmax_)) fits = false;
         }
         chain_v2_layer[i] = fits;
         if (const char* e = getenv("DVBS2_CHAIN_ONLY")) if (atoi(e) != i) chain_v2_layer[i] = 0; // debugging: one layer only
@@ -350,7 +350,7 @@ LdpcDecoderHip::LdpcDecoderHip(const LdpcTableDesc* table, int out_bits_message,
             auto is_mixed = [&](int k) { const int thr = 360 - (int)sched_.entries[L.entry_off + k].rot; return lo < thr && thr <= hi; };
             if (v2p) { for (int k = ncv; k < L.cnt; k++) { const int e = layer_order[i][k]; (is_mixed(e) ? mixed : plain).push_back(e); } }
             else for (int k = chain2 ? 2 : 0; k < L.cnt; k++) (is_mixed(k) ? mixed : plain).push_back(k);
-            const int nfix = v2p ? std::min(dmax_ / 2, (int)L.cnt) - ncv : std::min(dmax_ / 4, (int)L.cnt);
+            const int nfix = v2p ? std::min(dmax_ / 2, (int)L.cnt) - ncv : std::min(v2_nfix(dmax_), (int)L.cnt);
             if (!chain2 && (int)mixed.size() > nfix) continue; // (a chain layer was checked for every wave beforehand)
             std::fill(rec + 4, rec + RSW, 0u);
             rec[0] = hr[(size_t)i * RS] | (1u << 13) | (v2p ? 1u << 14 : 0u);

@@ -482,7 +482,10 @@ __device__ __forceinline__ int fix_wrap(int ad, uint32_t mlo, uint32_t mhi)
     return ad;
 }
 
-constexpr int v2_nfix(int dmax) { return dmax / 4; } // fix slots per record: masks live in record words 4 + dmax + 2 k
+#ifndef DVBS2_V2_NFIX32
+#define DVBS2_V2_NFIX32 10 // fix slots of the degree class 32: with 10 every wave record of S2X 154/180 fits the packed format (8: two of its 150 did not)
+#endif
+__host__ __device__ constexpr int v2_nfix(int dmax) { return dmax == 32 ? DVBS2_V2_NFIX32 : dmax / 4; } // fix slots per record: masks live in record words 4 + dmax + 2 k
 
 // Message storage of the packed nodes. A stored message is clamp(out, -32, 31) (R7): six bits. P6 = true keeps them as six-bit
 // two's complement fields, five per dword (entry e in word e / 5 at bit 6 (e % 5); a last word with one or two fields is a
@@ -1582,7 +1585,10 @@ __global__ __launch_bounds__(SOLO ? kSoloThreads : kThreads, SOLO ? 4 : MINW) vo
     // "pure" packed builds (DVBS2_V2_PURE_MIN_DMAX; hardware barriers only): the plain nodes are compiled for layer 0 only -- the plain hazard
     // nodes of the degree class 32 cost the packed ones around them 5 % through register allocation --; the host runs such a build only
     // for tables whose every (layer > 0, wave) record fits the packed format (ldpc_hip.hip)
-    constexpr bool kPure = V2 && !SOFT && v2_pure_class(DMAX);
+#ifndef DVBS2_V2_PURE_SOFT
+#define DVBS2_V2_PURE_SOFT 1 // also the software-barrier packed build of the pure classes (S2X 154/180 131.8 -> 133.9 k with ten fix slots, round 5)
+#endif
+    constexpr bool kPure = V2 && (!SOFT || DVBS2_V2_PURE_SOFT) && v2_pure_class(DMAX);
     constexpr bool TC = V2 && DMAX <= DVBS2_TC_MAX_DMAX;        // LLR bytes in LDS as two's complement (see lds_rdx)
     constexpr uint32_t kObState = TC ? 0x80808080u : 0u;        // LDS bytes <-> the offset-binary state in HBM
     int solo_tid = (int)threadIdx.x;
