@@ -47,6 +47,10 @@ private:
     uint16_t* d_log_ = nullptr;
     uint16_t* d_quad_ = nullptr;
     uint16_t* d_hcol_ = nullptr;  // parity-check columns for the syndrome stage (32 B per codeword bit)
+    int8_t* d_hrows_ = nullptr;   // the same matrix by rows, one byte per bit (batched syndromes on the matrix cores, bch_syndrome_kernel)
+    uint32_t* d_synd_ = nullptr;  // 8 dwords per frame: the odd syndromes of the batch
+    int synd_kp_ = 0, synd_rt_ = 0;
+    int synd_min_frames_ = 0;     // batches of at least this many frames take the product; smaller ones the per-set-bit table
     uint8_t* d_scramble_ = nullptr;
     bool descramble_ = false;
     int n_cus_ = 0;

@@ -6,7 +6,9 @@
 //
 // Mapping: persistent workgroups of 1024 threads, one per CU, each keeping the antilog table of the field
 // (2^m - 1 entries, 128 KB for GF(2^16)) in LDS for its whole life; frames are dealt round-robin.
-//   syndromes   S_i = r(alpha^i), i odd: every thread owns a stride of codeword bytes and adds
+//   syndromes   batches of >= 32 frames: all odd syndromes of all frames as ONE binary matrix product on the matrix cores
+//               (bch_syndrome_kernel, below); smaller batches inside the per-frame kernel:
+//               S_i = r(alpha^i), i odd: every thread owns a stride of codeword bytes and adds
 //               alpha^(i*e mod P) for each set bit of exponent e (== remainder-then-evaluate of the
 //               reference, lib/bch.cc:176-189,217-222: rem(alpha^i) = r(alpha^i), and rem == 0 <=> all S_i == 0);
 //               S_2i = S_i^2.
@@ -17,6 +19,7 @@
 #include "bch_hip.h"
 #include "device_guard.h"
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 namespace dvbs2 {
@@ -82,6 +85,8 @@ struct BchArgs {
                                               // bytes (the LDPC decoder's state, information part in natural order): bit = byte < 0x80
     const uint4* hcol;         // parity-check columns: hcol[2 e], hcol[2 e + 1] = alpha^(e), alpha^(3 e), .., alpha^((2t-1) e) as 16-bit halves (32 B per bit)
     const uint8_t* descramble; // k/8 bytes of the BB PRBS or nullptr (fused bbdescrambler_bb)
+    const uint32_t* synd;      // non-null: the odd syndromes of every frame, computed by bch_syndrome_kernel (8 dwords per frame: S_(2u+1)
+                               // in half u & 1 of dword u >> 1)
     int n_frames, m, P, t, n, k, s;
 };
 
@@ -106,6 +111,106 @@ __device__ __forceinline__ int wave_max(int x)
     int v = x;
     v = max(v, bch_dpp<0xB1>(v)); v = max(v, bch_dpp<0x4E>(v)); v = max(v, bch_dpp<0x141>(v)); v = max(v, bch_dpp<0x140>(v));
     return max(max(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)), max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+
+// ---- odd syndromes of a whole batch as ONE matrix product over GF(2) on the matrix cores ----
+// S = H c: H is the 16 t x n binary parity-check matrix (row 16 u + b = bit b of alpha^((2u+1) e) along the codeword), c the n x n_frames
+// matrix of hard decisions. One 32-byte table read per SET BIT and frame (above) costs a clean 8PSK 3/4 batch 0.55 ms per 4096 frames; as
+// a product the table is read once per 32 frames: v_mfma_i32_32x32x32_i8 on 0 / 1 bytes, the syndrome bit is the PARITY of the exact
+// integer sum (<= n < 2^31). A = 32 rows of H (bytes, zero-padded to a multiple of 128 columns and 32 rows), B = 32 frames: the LLR
+// bytes of the LDPC decoder's state turn into 0 / 1 with two instructions per dword (or packed codeword bytes are spread); both operands
+// give lane (r, h) the 64 consecutive columns k0 + 64 h .. of row / frame r, sixteen per instruction -- the K order inside an
+// instruction does not matter as long as A and B agree. A wave owns 32 frames x all rows x a chunk of the columns and xors its parities
+// into the frame's eight syndrome dwords (zeroed by the host before the launch); the four waves of a workgroup share the rows of H.
+using bch_v4i = __attribute__((ext_vector_type(4))) int;
+using bch_v16i = __attribute__((ext_vector_type(16))) int;
+constexpr int kSynK = 128; // columns per step of a wave
+
+template <int RT /*row tiles of 32: 16 t / 32 rounded up*/, bool PACKED>
+__global__ __launch_bounds__(256, 2) void bch_syndrome_kernel(const int8_t* __restrict__ H, int Kp /*padded columns*/, const uint8_t* __restrict__ src,
+                                                              size_t stride /*bytes per frame of src*/, int nb /*PACKED: codeword bytes*/,
+                                                              int n_frames, int steps_per_chunk, uint32_t* __restrict__ synd)
+{
+    // The four waves of a workgroup own four tiles of 32 frames and the SAME columns: the 32 RT x 128 bytes of H that a step needs are
+    // fetched once per workgroup -- wave w brings sixteen-column slice w of every row tile -- and handed over in LDS already in operand
+    // order (two buffers, one barrier per step). Straight from the L2 every wave read them itself: 4.7 KB through the vector cache per
+    // instruction, 0.15 ms per 4096 frames of 8PSK 3/4.
+    __shared__ bch_v4i hs[2][RT * 4 * 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ft = (int)blockIdx.x * 4 + wave;
+    const bool wave_on = ft * 32 < n_frames; // (a wave without frames still fetches its share of H and takes part in the barriers)
+    const int r = lane & 31, h = lane >> 5;
+    int f = ft * 32 + r;
+    const bool fvalid = f < n_frames;
+    if (!fvalid) f = n_frames - 1; // (reads a valid frame, contributes nothing)
+    bch_v16i acc[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+        for (int i = 0; i < 16; i++) acc[rt][i] = 0;
+    const int s0 = (int)blockIdx.y * steps_per_chunk, s1 = min(s0 + steps_per_chunk, Kp / kSynK);
+    const uint8_t* fsrc = src + (size_t)f * stride;
+    constexpr int NRAW = PACKED ? 8 : 16;
+    bch_v4i hreg[RT];
+    uint32_t raw[NRAW];
+    auto fetch = [&](int st) {
+        const int k = st * kSynK + 64 * h;
+#pragma unroll
+        for (int rt = 0; rt < RT; rt++) hreg[rt] = *reinterpret_cast<const bch_v4i*>(H + (size_t)(rt * 32 + r) * (size_t)Kp + k + 16 * wave);
+        if (wave_on) {
+            if constexpr (!PACKED) {
+                const uint2* p = reinterpret_cast<const uint2*>(fsrc + k);
+#pragma unroll
+                for (int i = 0; i < 8; i++) { const uint2 w = p[i]; raw[2 * i] = w.x; raw[2 * i + 1] = w.y; }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; i++) { const int bi = (k >> 3) + i; raw[i] = bi < nb ? (uint32_t)fsrc[bi] : 0u; }
+            }
+        }
+    };
+    auto publish = [&](int buf) {
+#pragma unroll
+        for (int rt = 0; rt < RT; rt++) hs[buf][(rt * 4 + wave) * 64 + lane] = hreg[rt];
+    };
+    int buf = 0;
+    if (s0 < s1) { fetch(s0); publish(0); }
+    __syncthreads();
+    for (int st = s0; st < s1; st++) {
+        uint32_t b[16];
+        if constexpr (!PACKED) { // offset-binary LLR bytes (8-byte aligned rows): bit = 1 where the LLR is negative = bit 7 clear
+#pragma unroll
+            for (int i = 0; i < 16; i++) b[i] = (~raw[i] >> 7) & 0x01010101u;
+        } else { // packed bytes, first bit of the stream = bit 7: nibble n -> bytes (n >> 3) & 1, (n >> 2) & 1, (n >> 1) & 1, n & 1
+            auto spread = [](uint32_t nib) { return ((nib >> 3) & 1u) | ((nib & 4u) << 6) | ((nib & 2u) << 15) | ((nib & 1u) << 24); };
+#pragma unroll
+            for (int i = 0; i < 8; i++) { b[2 * i] = spread(raw[i] >> 4); b[2 * i + 1] = spread(raw[i] & 15u); }
+        }
+        if (st + 1 < s1) fetch(st + 1); // in flight while this step multiplies
+        if (wave_on) {
+#pragma unroll
+            for (int rt = 0; rt < RT; rt++) {
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    bch_v4i bv; bv[0] = (int)b[4 * i]; bv[1] = (int)b[4 * i + 1]; bv[2] = (int)b[4 * i + 2]; bv[3] = (int)b[4 * i + 3];
+                    acc[rt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(hs[buf][(rt * 4 + i) * 64 + lane], bv, acc[rt], 0, 0, 0);
+                }
+            }
+        }
+        if (st + 1 < s1) publish(buf ^ 1); // (everybody left that buffer at the previous barrier)
+        __syncthreads();
+        buf ^= 1;
+    }
+    // D: column (frame) = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+    if (fvalid && wave_on) {
+#pragma unroll
+        for (int rt = 0; rt < RT; rt++) {
+            uint32_t bits = 0;
+#pragma unroll
+            for (int i = 0; i < 16; i++) bits |= ((uint32_t)acc[rt][i] & 1u) << ((i & 3) + 8 * (i >> 2));
+            bits <<= 4 * h;
+            if (bits) atomicXor(&synd[(size_t)f * 8 + rt], bits);
+        }
+    }
 }
 
 __global__ __launch_bounds__(kBchThreads) void bch_decode_kernel(BchArgs a)
@@ -156,6 +261,9 @@ __global__ __launch_bounds__(kBchThreads) void bch_decode_kernel(BchArgs a)
         // the L2) -- one 32-byte read per set bit instead of t exponent products, reductions mod P and random 16-bit LDS gathers: a real
         // codeword has n / 2 set bits, and the gathers made the syndromes 0.9 ms per 4096 frames of 8PSK 3/4 (a ninth of the chain's step at
         // its operating point) whether the word was clean or not. (Measured 0.11 ms "when clean" in earlier rounds was the all-zero word.)
+        if (a.synd) { // computed for the whole batch by bch_syndrome_kernel
+            if (tid < t) S[2 * tid] = (a.synd[(size_t)f * 8 + (tid >> 1)] >> (16 * (tid & 1))) & 0xffffu;
+        } else {
         uint32_t acc[kMaxT / 2 + 2];
 #pragma unroll
         for (int u = 0; u < kMaxT / 2 + 2; u++) acc[u] = 0;
@@ -181,6 +289,7 @@ __global__ __launch_bounds__(kBchThreads) void bch_decode_kernel(BchArgs a)
                 }
             }
         }
+        } // (!a.synd)
         __syncthreads();
 
         if (tid < 64) { // the first wavefront; lane c owns coefficient column c of the Berlekamp rows and the bookkeeping of row c
@@ -359,6 +468,25 @@ BchDecoderHip::BchDecoderHip(int m, uint32_t prim_poly, int t, int n, int max_fr
         HIP_OK(hipMalloc(&d_hcol_, hc.size() * 2));
         HIP_OK(hipMemcpy(d_hcol_, hc.data(), hc.size() * 2, hipMemcpyHostToDevice));
     }
+    {   // ... and by rows as 0 / 1 bytes for the batched product: row 16 u + b = bit b of alpha^((2u+1) e), column = stream position
+        // p = n - 1 - e; rows padded to a multiple of 32, columns to a multiple of kSynK (the padding is zero: whatever the frames hold
+        // behind their n bits does not count)
+        synd_rt_ = (16 * code_.t + 31) / 32;
+        synd_kp_ = (code_.n + kSynK - 1) / kSynK * kSynK;
+        std::vector<int8_t> hr((size_t)synd_rt_ * 32 * synd_kp_, 0);
+        for (int p = 0; p < code_.n; p++) {
+            const uint64_t e = (uint64_t)(code_.n - 1 - p);
+            for (int u = 0; u < code_.t; u++) {
+                const uint32_t v = code_.antilog[(uint32_t)(((uint64_t)(2 * u + 1) * e) % (uint64_t)code_.P)];
+                for (int b = 0; b < code_.m; b++) hr[(size_t)(16 * u + b) * synd_kp_ + p] = (int8_t)((v >> b) & 1u);
+            }
+        }
+        HIP_OK(hipMalloc(&d_hrows_, hr.size()));
+        HIP_OK(hipMemcpy(d_hrows_, hr.data(), hr.size(), hipMemcpyHostToDevice));
+        HIP_OK(hipMalloc(&d_synd_, (size_t)max_frames_ * 32));
+        synd_min_frames_ = 32;
+        if (const char* ev = getenv("DVBS2_BCH_SYND_MIN")) synd_min_frames_ = std::max(1, atoi(ev)); // tests: 1 = always the product, 1000000 = never
+    }
     lds_bytes_ = (((size_t)code_.P * 2 + 15) & ~(size_t)15) + kBchWorkWords * 4 + (size_t)((code_.n / 8 + 15) & ~15);
     HIP_OK(hipFuncSetAttribute((const void*)bch_decode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes_));
 #undef HIP_OK
@@ -399,7 +527,7 @@ BchDecoderHip::~BchDecoderHip()
 {
     DeviceGuard dev_guard(device_);
     (void)hipFree(d_scramble_);
-    (void)hipFree(d_antilog_); (void)hipFree(d_log_); (void)hipFree(d_quad_); (void)hipFree(d_hcol_);
+    (void)hipFree(d_antilog_); (void)hipFree(d_log_); (void)hipFree(d_quad_); (void)hipFree(d_hcol_); (void)hipFree(d_hrows_); (void)hipFree(d_synd_);
 }
 
 int BchDecoderHip::decode_device(const uint8_t* d_cw, int n_frames, uint8_t* d_msg, int32_t* d_corr, hipStream_t stream,
@@ -415,6 +543,28 @@ int BchDecoderHip::decode_device(const uint8_t* d_cw, int n_frames, uint8_t* d_m
     a.antilog = d_antilog_; a.log = d_log_; a.quad = d_quad_; a.hcol = reinterpret_cast<const uint4*>(d_hcol_); a.cw = d_cw; a.msg = d_msg; a.corr = d_corr; a.llr_state = d_llr_state; a.llr_stride = llr_stride;
     a.descramble = descramble_ ? d_scramble_ : nullptr;
     a.n_frames = n_frames; a.m = code_.m; a.P = code_.P; a.t = code_.t; a.n = code_.n; a.k = code_.k; a.s = code_.s;
+    a.synd = nullptr;
+    if (n_frames >= synd_min_frames_ && (d_cw != nullptr || (llr_stride >= synd_kp_ && llr_stride % 8 == 0))) {
+        // the odd syndromes of the whole batch first (bch_syndrome_kernel): 32 frames per wave, the columns cut into chunks so that the
+        // launch has about eight waves per CU
+        const int tiles = (n_frames + 31) / 32, steps = synd_kp_ / kSynK;
+        const int chunks = std::max(1, std::min(steps, (8 * std::max(1, n_cus_) + tiles - 1) / tiles));
+        const int spc = (steps + chunks - 1) / chunks;
+        const dim3 sgrid((tiles + 3) / 4, (steps + spc - 1) / spc);
+        if (hipMemsetAsync(d_synd_, 0, (size_t)n_frames * 32, stream) != hipSuccess) { call_err_ = "bch syndrome buffer reset failed"; return -1; }
+        const bool packed = d_cw != nullptr;
+        const uint8_t* src = packed ? d_cw : d_llr_state;
+        const size_t stride = packed ? (size_t)(code_.n / 8) : (size_t)llr_stride;
+#define DVBS2_SYN_LAUNCH(RT) do { \
+            if (packed) hipLaunchKernelGGL((bch_syndrome_kernel<RT, true>), sgrid, dim3(256), 0, stream, d_hrows_, synd_kp_, src, stride, code_.n / 8, n_frames, spc, d_synd_); \
+            else hipLaunchKernelGGL((bch_syndrome_kernel<RT, false>), sgrid, dim3(256), 0, stream, d_hrows_, synd_kp_, src, stride, code_.n / 8, n_frames, spc, d_synd_); } while (0)
+        switch (synd_rt_) {
+            case 1: DVBS2_SYN_LAUNCH(1); break; case 2: DVBS2_SYN_LAUNCH(2); break; case 3: DVBS2_SYN_LAUNCH(3); break;
+            case 4: DVBS2_SYN_LAUNCH(4); break; case 5: DVBS2_SYN_LAUNCH(5); break; default: DVBS2_SYN_LAUNCH(6); break;
+        }
+#undef DVBS2_SYN_LAUNCH
+        a.synd = d_synd_;
+    }
     const int grid = std::min(n_frames, std::max(1, n_cus_));
     hipLaunchKernelGGL(bch_decode_kernel, dim3(grid), dim3(kBchThreads), lds_bytes_, stream, a);
     hipError_t e = hipGetLastError();

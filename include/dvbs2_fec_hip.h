@@ -174,6 +174,9 @@ int dvbs2_bch_set_descramble(dvbs2_bch_t* h, int enable);
 /* the BBFRAME energy-dispersal sequence itself (1 + x^14 + x^15, register 100101010000000, packed MSB first;
  * reference init_bb_derandomiser(), lib/bbdescrambler_bb_impl.cc:51-65), host only; n_bytes <= 8100 */
 int dvbs2_bb_descramble_sequence(uint8_t* seq, int n_bytes);
+/* Device pointers, asynchronous on `stream`. The handle owns the batch's syndrome words (batches of 32 frames and more compute the odd
+ * syndromes of all frames as one GF(2) matrix product before the per-frame stage): calls of ONE handle must be ordered -- the same
+ * stream, or synchronised by the caller --; concurrent batches take one handle each. */
 int dvbs2_bch_decode_device(dvbs2_bch_t* h, const uint8_t* d_cw, int n_frames, uint8_t* d_msg,
                             int32_t* d_corrections, void* stream);
 

@@ -21,7 +21,10 @@ def bch_pair(framesize, rate):
 @pytest.mark.parametrize("framesize,rate", [(capi.FECFRAME_NORMAL, "C1_2"), (capi.FECFRAME_NORMAL, "C3_4"),
                                             (capi.FECFRAME_NORMAL, "C9_10"), (capi.FECFRAME_SHORT, "C1_4"),
                                             (capi.FECFRAME_NORMAL, "C2_3"), (capi.FECFRAME_SHORT, "C8_9")])
-def test_bch_error_patterns(framesize, rate):
+@pytest.mark.parametrize("syndromes", ["table", "product"])
+def test_bch_error_patterns(framesize, rate, syndromes, monkeypatch):
+    # both syndrome stages on the same words: one table read per set bit (small batches), the batched GF(2) matrix product (>= 32 frames)
+    monkeypatch.setenv("DVBS2_BCH_SYND_MIN", "1" if syndromes == "product" else "1000000")
     ob, fi = bch_pair(framesize, rate)
     t, n, k = fi["bch_t"], fi["bch_n"], fi["bch_k"]
     rng = np.random.default_rng(17)
@@ -48,6 +51,27 @@ def test_bch_error_patterns(framesize, rate):
     ok = [i for i, c in enumerate(counts) if c <= t]
     assert np.array_equal(out[ok], msg[ok]) and ret[ok].tolist() == [counts[i] for i in ok]
     assert dec.frame_error_cnt == int((wret == -1).sum())
+    dec.close()
+
+
+@pytest.mark.parametrize("framesize,rate,nf", [(capi.FECFRAME_NORMAL, "C3_4", 77), (capi.FECFRAME_SHORT, "C1_4", 133),
+                                               (capi.FECFRAME_NORMAL, "C9_10", 33), (capi.FECFRAME_NORMAL, "C3_5", 64)])
+def test_bch_batched_syndromes_ragged_batches(framesize, rate, nf):
+    """The batched syndrome product (32 frames per wave, columns cut into chunks, partial last tile) on batches that are no multiple of 32:
+    0 .. t + 2 errors per word, every frame against the oracle; a second call on the same handle with fewer frames (stale syndrome words
+    of the first call must not leak)."""
+    ob, fi = bch_pair(framesize, rate)
+    t, n, k = fi["bch_t"], fi["bch_n"], fi["bch_k"]
+    rng = np.random.default_rng(nf)
+    msg = rng.integers(0, 256, (nf, k // 8), dtype=np.uint8)
+    cw = ob.encode_bytes(msg)
+    rx = np.stack([T.flip_bits(cw[i], rng.choice(n, int(rng.integers(0, t + 3)), replace=False)) for i in range(nf)])
+    dec = BchDecoder(framesize=framesize, rate=rate, max_frames=nf)
+    for m in (nf, 40 if nf > 40 else 32):
+        out, ret = dec.work(rx[:m])
+        want, wret = ob.decode_bytes(rx[:m])
+        assert ret.tolist() == wret.tolist()
+        assert np.array_equal(out, want)
     dec.close()
 
 

@@ -7,4 +7,5 @@ O=gpurun_out/${1:-r5fuzz}; mkdir -p $O
 (DVBS2_PR=0 DVBS2_DENSE=0 DVBS2_HZ2=0 DVBS2_V2=0 DVBS2_SOLO=0 python tools/fuzz_ldpc.py ${FUZZ_S:-300} 54 2>&1 | tail -3) > $O/fuzz_plain.log &
 wait
 python tools/fuzz_bch.py 45 2>&1 | tail -2 > $O/fuzz_bch.log
+DVBS2_BCH_SYND_MIN=1 python tools/fuzz_bch.py 45 2>&1 | tail -2 > $O/fuzz_bch_product.log   # syndromes through the batched matrix product
 for f in $O/*.log; do echo "$f: $(tail -1 $f)"; done
