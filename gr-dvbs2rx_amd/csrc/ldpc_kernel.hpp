@@ -51,6 +51,10 @@
 // s_waitcnt vmcnt(0) (expcnt, lgkmcnt untouched) that memory operations are not moved across
 // (kWaitStore in scope: not in the builds with software frame barriers -- S2X 154/180 lost 4 % with it)
 #define DVBS2_WAIT_VM0() do { if (kWaitStore) { asm volatile("" ::: "memory"); __builtin_amdgcn_s_waitcnt(0x0f70); asm volatile("" ::: "memory"); } } while (0)
+#ifndef DVBS2_TLC_FWALK_MIN_DMAX
+#define DVBS2_TLC_FWALK_MIN_DMAX 24 // the near pair of a two-level lane chain walked in float (six instructions per row, 16-byte operand records) in the
+                                    // packed hazard nodes from this degree class up -- measured (round 5): 5/6 normal +3.1 %, 9/10 normal +0.35 %; 3/4 normal (class 16) -2.0 %
+#endif
 #ifndef DVBS2_TLC_SOFT
 #define DVBS2_TLC_SOFT 0 // experiments: the two-level lane chain also in the builds with software frame barriers
 #endif
@@ -1138,7 +1142,11 @@ __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, con
     if constexpr (kTlcBuilt) tlc = block2 > 0 && tab != nullptr; // wave-uniform
     if constexpr (kTlcBuilt) if (tlc) {
         lds_byte_t* ulog = reinterpret_cast<lds_byte_t*>(tab + kM + block);
+        constexpr bool kTlcFloat = V2P && DMAXV >= DVBS2_TLC_FWALK_MIN_DMAX;
+        lds_v4f_t* trec = lds_align16<lds_v4f_t>(tab);                                      // kTlcFloat: [360 + block] operand records { sigma, -sigma m1, P + 1, inp0 + 128 }
+        lds_f32_t* tlog = reinterpret_cast<lds_f32_t*>(trec) + 4 * (kM + kChainMaxBlock); //            [360 + block] the value that arrived at a row
         int chained = 0x80;
+        float cf = 0.f;
         const bool head = work && jj < block;
         int rnext = jj + block; // chain lanes: the next row to visit
         for (int sb = 0; sb < kM; sb += block2) {
@@ -1170,11 +1178,30 @@ __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, con
                     hout[0] = (o0 ^ s0) - s0;
                     hout[1] = (o1 ^ s1) - s1;
                     chained = sat_sum_u8(inp[0], hout[0]);
+                    cf = (float)chained;
                     lds_wrx<TC>(ad[1], sat_sum_u8(inp[1], hout[1]));
+                } else if constexpr (kTlcFloat) {
+                    const float sigma = as_f32(0x3f800000u | ((uint32_t)signsF & 0x80000000u));
+                    v4f32 r;
+                    r.x = sigma; r.y = -sigma * (float)hmb[1]; r.z = (float)(minF + 1); r.w = (float)(inp[0] + 128);
+                    trec[jj] = r;
                 } else
                     tab[jj] = ((uint32_t)inp[0] & 0x1ffu) | ((uint32_t)minF << 9) | (((uint32_t)signsF >> 31) << 16) | ((uint32_t)hmb[1] << 24);
             }
             lds_barrier();
+            if constexpr (kTlcFloat) { if (head && rnext < sb_end) {
+                // (as the single-pair chains: x = sigma (c - m1), w = clamp(x, -(P+1), P+1), out = w - sgn(w), c' = clamp(inp0 + 128 + out, 0, 255))
+                v4f32 q = trec[rnext];
+                for (; rnext < sb_end; rnext += block) {
+                    const v4f32 rc = q;
+                    q = trec[rnext + block]; // next row's record (valid when that row belongs to this outer block; reloaded otherwise)
+                    tlog[rnext] = cf;
+                    const float x = __builtin_fmaf(cf, rc.x, rc.y);
+                    const float w = vmed3_f32(x, -rc.z, rc.z);
+                    const float f = w - vmed3_f32(w, -1.f, 1.f);
+                    cf = vmed3_f32(rc.w + f, 0.f, 255.f);
+                }
+            } } else
             if (head && rnext < sb_end) {
                 uint32_t t = tab[rnext];
                 for (; rnext < sb_end; rnext += block) {
@@ -1194,7 +1221,7 @@ __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, con
             lds_barrier();
             if (in_sb) {
                 if (!head) {
-                    const int L1 = ulog[jj];
+                    const int L1 = kTlcFloat ? (int)tlog[jj] : (int)ulog[jj];
                     inp[1] = min(max(L1 - hmb[1], -128), 127);
                     mg[1] = mag_raw(L1, hmb[1]);
                     int o0, o1;
