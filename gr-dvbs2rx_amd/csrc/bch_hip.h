@@ -35,8 +35,12 @@ public:
     // have thrown (lib/gf.h:110 via lib/bch.cc:359-367, or lib/bch.cc:443-444).
     // d_cw == nullptr: the codewords are the hard decisions of d_llr_state (offset-binary LLR bytes, llr_stride per frame: the LDPC
     // decoder's state) -- ldpc_decoder_bb's bit packing fused into this kernel's load
+    // frame_base: which range [frame_base, frame_base + n_frames) of the handle's per-frame syndrome words the call uses (the odd syndromes
+    // of a batch are computed as one matrix product BEFORE the per-frame stage). Calls on disjoint ranges may be in flight together on
+    // different streams (the chunks of the host-pointer chain entry); a call whose range overlaps that of an earlier call on ANOTHER
+    // stream is ordered behind it with an event (two streams on one handle must not corrupt each other's syndromes).
     int decode_device(const uint8_t* d_cw, int n_frames, uint8_t* d_msg, int32_t* d_corr, hipStream_t stream,
-                      const uint8_t* d_llr_state = nullptr, int llr_stride = 0);
+                      const uint8_t* d_llr_state = nullptr, int llr_stride = 0, int frame_base = 0);
     // fuse bbdescrambler_bb (lib/bbdescrambler_bb_impl.cc:67-82) into the output stage: msg ^= PRBS
     int set_descramble(bool enable);
 
@@ -55,6 +59,10 @@ private:
     bool descramble_ = false;
     int n_cus_ = 0;
     size_t lds_bytes_ = 0;
+    struct InFlight { hipStream_t stream = nullptr; hipEvent_t done = nullptr; int base = 0, n = 0; };
+    static constexpr int kTrack = 8;
+    InFlight track_[kTrack];   // the last kTrack calls: stream, syndrome range, completion event
+    int track_next_ = 0;
     std::string err_;      // set by the constructor only
     std::string call_err_; // last failed call
 };

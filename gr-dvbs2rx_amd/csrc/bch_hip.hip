@@ -542,17 +542,24 @@ BchDecoderHip::~BchDecoderHip()
     DeviceGuard dev_guard(device_);
     (void)hipFree(d_scramble_);
     (void)hipFree(d_antilog_); (void)hipFree(d_log_); (void)hipFree(d_quad_); (void)hipFree(d_hcol_); (void)hipFree(d_hrows_); (void)hipFree(d_synd_);
+    for (InFlight& t : track_) if (t.done) (void)hipEventDestroy(t.done);
 }
 
 int BchDecoderHip::decode_device(const uint8_t* d_cw, int n_frames, uint8_t* d_msg, int32_t* d_corr, hipStream_t stream,
-                                 const uint8_t* d_llr_state, int llr_stride)
+                                 const uint8_t* d_llr_state, int llr_stride, int frame_base)
 {
     if (!ok()) return -1;
     call_err_.clear();
-    if (n_frames < 0 || n_frames > max_frames_) { call_err_ = "n_frames exceeds max_frames"; return -1; }
+    if (n_frames < 0 || frame_base < 0 || frame_base + n_frames > max_frames_) { call_err_ = "n_frames exceeds max_frames"; return -1; }
     if (n_frames == 0) return 0;
     DeviceGuard dev_guard(device_);
     if (!dev_guard.ok) { call_err_ = "hipSetDevice failed"; return -1; }
+    // the syndrome words of [frame_base, frame_base + n_frames) belong to this call until its per-frame kernel has read them: an earlier
+    // call on ANOTHER stream that used an overlapping range is waited for on the device (same stream: stream order already does it)
+    for (const InFlight& t : track_)
+        if (t.done && t.stream != stream && t.base < frame_base + n_frames && frame_base < t.base + t.n)
+            if (hipStreamWaitEvent(stream, t.done, 0) != hipSuccess) { call_err_ = "hipStreamWaitEvent failed"; return -1; }
+    uint32_t* const synd = d_synd_ + (size_t)frame_base * 8;
     BchArgs a;
     a.antilog = d_antilog_; a.log = d_log_; a.quad = d_quad_; a.hcol = reinterpret_cast<const uint4*>(d_hcol_); a.cw = d_cw; a.msg = d_msg; a.corr = d_corr; a.llr_state = d_llr_state; a.llr_stride = llr_stride;
     a.descramble = descramble_ ? d_scramble_ : nullptr;
@@ -565,24 +572,31 @@ int BchDecoderHip::decode_device(const uint8_t* d_cw, int n_frames, uint8_t* d_m
         const int chunks = std::max(1, std::min(steps, (8 * std::max(1, n_cus_) + tiles - 1) / tiles));
         const int spc = (steps + chunks - 1) / chunks;
         const dim3 sgrid((tiles + 3) / 4, (steps + spc - 1) / spc);
-        if (hipMemsetAsync(d_synd_, 0, (size_t)n_frames * 32, stream) != hipSuccess) { call_err_ = "bch syndrome buffer reset failed"; return -1; }
+        if (hipMemsetAsync(synd, 0, (size_t)n_frames * 32, stream) != hipSuccess) { call_err_ = "bch syndrome buffer reset failed"; return -1; }
         const bool packed = d_cw != nullptr;
         const uint8_t* src = packed ? d_cw : d_llr_state;
         const size_t stride = packed ? (size_t)(code_.n / 8) : (size_t)llr_stride;
 #define DVBS2_SYN_LAUNCH(RT) do { \
-            if (packed) hipLaunchKernelGGL((bch_syndrome_kernel<RT, true>), sgrid, dim3(256), 0, stream, d_hrows_, synd_kp_, src, stride, code_.n / 8, n_frames, spc, d_synd_); \
-            else hipLaunchKernelGGL((bch_syndrome_kernel<RT, false>), sgrid, dim3(256), 0, stream, d_hrows_, synd_kp_, src, stride, code_.n / 8, n_frames, spc, d_synd_); } while (0)
+            if (packed) hipLaunchKernelGGL((bch_syndrome_kernel<RT, true>), sgrid, dim3(256), 0, stream, d_hrows_, synd_kp_, src, stride, code_.n / 8, n_frames, spc, synd); \
+            else hipLaunchKernelGGL((bch_syndrome_kernel<RT, false>), sgrid, dim3(256), 0, stream, d_hrows_, synd_kp_, src, stride, code_.n / 8, n_frames, spc, synd); } while (0)
         switch (synd_rt_) {
             case 1: DVBS2_SYN_LAUNCH(1); break; case 2: DVBS2_SYN_LAUNCH(2); break; case 3: DVBS2_SYN_LAUNCH(3); break;
             case 4: DVBS2_SYN_LAUNCH(4); break; case 5: DVBS2_SYN_LAUNCH(5); break; default: DVBS2_SYN_LAUNCH(6); break;
         }
 #undef DVBS2_SYN_LAUNCH
-        a.synd = d_synd_;
+        a.synd = synd;
     }
     const int grid = std::min(n_frames, std::max(1, n_cus_));
     hipLaunchKernelGGL(bch_decode_kernel, dim3(grid), dim3(kBchThreads), lds_bytes_, stream, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { call_err_ = std::string("bch kernel launch: ") + hipGetErrorString(e); return -1; }
+    {
+        InFlight& t = track_[track_next_];
+        track_next_ = (track_next_ + 1) % kTrack;
+        if (!t.done && hipEventCreateWithFlags(&t.done, hipEventDisableTiming) != hipSuccess) { t.done = nullptr; call_err_ = "hipEventCreate failed"; (void)hipStreamSynchronize(stream); return -1; }
+        t.stream = stream; t.base = frame_base; t.n = n_frames;
+        if (hipEventRecord(t.done, stream) != hipSuccess) { call_err_ = "hipEventRecord failed"; (void)hipStreamSynchronize(stream); return -1; }
+    }
     return 0;
 }
 

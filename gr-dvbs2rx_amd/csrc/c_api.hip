@@ -441,6 +441,57 @@ int dvbs2_measure_host_copy(int device, size_t bytes, int n_streams, int kind, d
     API_CATCH
 }
 
+} // extern "C"
+
+// every SIMD of the device busy with dependent VALU adds; workgroup 0 reports its s_memtime (shader clock) and s_memrealtime (100 MHz) deltas
+__global__ void dvbs2_clock_probe_kernel(unsigned long long* out, int n)
+{
+    unsigned long long r0, r1;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r0));
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    uint32_t a = threadIdx.x;
+    for (int i = 0; i < n; i++) asm volatile("v_add_u32 %0, %0, 1\n\tv_add_u32 %0, %0, 1\n\tv_add_u32 %0, %0, 1\n\tv_add_u32 %0, %0, 1" : "+v"(a));
+    const unsigned long long t1 = __builtin_readcyclecounter();
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r1));
+    if (blockIdx.x == 0 && threadIdx.x == 0) { out[0] = t1 - t0; out[1] = r1 - r0; out[2] = a; }
+}
+
+extern "C" {
+
+int dvbs2_measure_shader_clock(int device, double* ghz, double* kernel_ms)
+{
+    API_TRY
+    if (!ghz) return fail(DVBS2_EINVAL, "bad argument");
+    DeviceGuard guard(device);
+    if (!guard.ok) return fail(DVBS2_EDEVICE, "hipSetDevice failed");
+    unsigned long long* d = nullptr; unsigned long long hv[3] = {};
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    float ms = 0;
+    auto body = [&]() -> int {
+        HCHK(hipMalloc(&d, 64));
+        HCHK(hipEventCreate(&e0)); HCHK(hipEventCreate(&e1));
+        for (int rep = 0; rep < 2; rep++) { // (the first launch lets the clock ramp)
+            HCHK(hipEventRecord(e0, nullptr));
+            hipLaunchKernelGGL(dvbs2_clock_probe_kernel, dim3(2048), dim3(256), 0, nullptr, d, 300000);
+            HCHK(hipEventRecord(e1, nullptr));
+            HCHK(hipEventSynchronize(e1));
+        }
+        HCHK(hipEventElapsedTime(&ms, e0, e1));
+        HCHK(hipMemcpy(hv, d, 24, hipMemcpyDeviceToHost));
+        return DVBS2_OK;
+    };
+    const int rc = body();
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (d) (void)hipFree(d);
+    if (rc != DVBS2_OK) return rc;
+    if (!hv[1]) return fail(DVBS2_EDEVICE, "clock probe returned nothing");
+    *ghz = (double)hv[0] / (double)hv[1] * 0.1; // s_memrealtime counts at 100 MHz
+    if (kernel_ms) *kernel_ms = ms;
+    return DVBS2_OK;
+    API_CATCH
+}
+
 int dvbs2_ldpc_profile(dvbs2_ldpc_t* h, int enable, double* total_ms, int* launches)
 {
     if (!h) return fail(DVBS2_EINVAL, "null handle");
@@ -741,6 +792,14 @@ struct dvbs2_chain {
     int device = 0, max_frames = 0, n_llr = 0, ldpc_bytes = 0, msg_bytes = 0;
     // the call between enqueue and finish
     bool pending = false; int n_frames = 0; uint8_t* d_msg = nullptr; int32_t* d_bch_corr = nullptr; void* stream = nullptr;
+    // host-pointer entries (dvbs2_chain_decode / dvbs2_chain_decode_llr): device copies of the caller's buffers, pinned landing buffers for
+    // the outputs of a pageable caller, one stream per chunk slot + one copy stream (the plan of dvbs2_ldpc_decode)
+    float* hd_syms = nullptr; int8_t* hd_llr = nullptr; float* hd_n0 = nullptr; uint8_t* hd_msg = nullptr; int32_t* hd_ret = nullptr; int32_t* hd_corr = nullptr;
+    uint8_t* p_msg = nullptr; int32_t* p_ret = nullptr; int32_t* p_corr = nullptr;
+    hipStream_t hstream[LdpcDecoderHip::kSlots] = {};
+    hipStream_t hcopy = nullptr;
+    hipEvent_t h_in_ready[LdpcDecoderHip::kSlots] = {};
+    int host_chunk = 0; // DVBS2_HOST_CHUNK (experiments, tests), read once at create
 };
 
 static int chain_make(dvbs2_chain_t** h, int standard, int framesize, int rate, int constellation, bool with_demap,
@@ -751,6 +810,7 @@ static int chain_make(dvbs2_chain_t** h, int standard, int framesize, int rate, 
     dvbs2_chain* o = new (std::nothrow) dvbs2_chain();
     if (!o) return fail(DVBS2_EDEVICE, "out of memory");
     o->device = device; o->max_frames = max_frames;
+    if (const char* e = getenv("DVBS2_HOST_CHUNK")) o->host_chunk = std::max(2, atoi(e));
     int rc = DVBS2_OK;
     if (with_demap) rc = dvbs2_demap_create(&o->dm, framesize, rate, constellation, max_frames, device);
     if (rc == DVBS2_OK) rc = dvbs2_ldpc_create(&o->ldpc, standard, framesize, rate, group_size, max_frames, device);
@@ -773,12 +833,14 @@ static int chain_make(dvbs2_chain_t** h, int standard, int framesize, int rate, 
 // LDPC (already enqueued) -> BCH on the same stream; the LDPC output never leaves HBM
 // BCH straight from the LDPC decoder's state (hard decision + packing of ldpc_decoder_bb fused into the BCH kernel's load: no
 // finalize launch, no packed-bit buffer in between)
-static int chain_bch(dvbs2_chain_t* h)
+static int chain_bch_range(dvbs2_chain_t* h, int frame_base, int n_frames, uint8_t* d_msg, int32_t* d_corr, hipStream_t stream)
 {
-    if (h->bch->dec->decode_device(nullptr, h->n_frames, h->d_msg, h->d_bch_corr, (hipStream_t)h->stream, h->ldpc->dec->state(), h->ldpc->dec->N()))
+    const int N = h->ldpc->dec->N();
+    if (h->bch->dec->decode_device(nullptr, n_frames, d_msg, d_corr, stream, h->ldpc->dec->state() + (size_t)frame_base * N, N, frame_base))
         return fail(DVBS2_EDEVICE, h->bch->dec->error());
     return DVBS2_OK;
 }
+static int chain_bch(dvbs2_chain_t* h) { return chain_bch_range(h, 0, h->n_frames, h->d_msg, h->d_bch_corr, (hipStream_t)h->stream); }
 
 // LDPC -> BCH on one stream; dm != nullptr: the LDPC sweep kernel demaps the symbols while it loads them
 static int chain_enqueue_tail(dvbs2_chain_t* h, const int8_t* d_llr, const DemapFused* dm, int n_frames, int max_trials, uint8_t* d_msg,
@@ -806,6 +868,13 @@ void dvbs2_chain_destroy(dvbs2_chain_t* h)
     DeviceGuard guard(h->device);
     dvbs2_demap_destroy(h->dm); dvbs2_ldpc_destroy(h->ldpc); dvbs2_bch_destroy(h->bch);
     (void)hipFree(h->d_llr); (void)hipFree(h->d_bits); (void)hipFree(h->d_corr);
+    (void)hipFree(h->hd_syms); (void)hipFree(h->hd_llr); (void)hipFree(h->hd_n0); (void)hipFree(h->hd_msg); (void)hipFree(h->hd_ret); (void)hipFree(h->hd_corr);
+    if (h->p_msg) (void)hipHostFree(h->p_msg);
+    if (h->p_ret) (void)hipHostFree(h->p_ret);
+    if (h->p_corr) (void)hipHostFree(h->p_corr);
+    for (hipStream_t st : h->hstream) if (st) (void)hipStreamDestroy(st);
+    if (h->hcopy) (void)hipStreamDestroy(h->hcopy);
+    for (hipEvent_t ev : h->h_in_ready) if (ev) (void)hipEventDestroy(ev);
     delete h;
 }
 
@@ -914,6 +983,160 @@ int dvbs2_chain_decode_llr_device(dvbs2_chain_t* h, const int8_t* d_llr, int n_f
     int rc = dvbs2_chain_enqueue_llr_device(h, d_llr, n_frames, max_trials, d_msg, d_ldpc_ret, d_bch_corr, stream);
     if (rc != DVBS2_OK) { if (h) h->pending = false; return rc; }
     return dvbs2_chain_finish(h);
+}
+
+} // extern "C"
+
+// Host-pointer form of the fused chain (SURVEY 8(b) "dvbs2_fec_chain_decode(syms -> msg bytes)"): what the three blocks do with the
+// item buffers GNU Radio hands them (lib/xfecframe_demapper_cb_impl.cc:101-186 -> lib/ldpc_decoder_bb_impl.cc:394-455 ->
+// lib/bch_decoder_bb_impl.cc:84-117), as ONE call. The call is cut into chunks of whole LDPC groups exactly like dvbs2_ldpc_decode:
+// chunk c runs on stream c mod kSlots in its own range of the LDPC state / message buffers and of the BCH syndrome words, its input
+// copy (through one copy stream when the caller's buffer is page-locked) runs under the kernels of chunk c - 1 and its results go
+// back while chunk c + 1 decodes. An 8PSK normal frame is 172.8 KB of symbols in and ~6 KB out: at the ~57 GB/s of the host link the
+// chain is LINK-bound near 320 k frames/s -- below what the kernels do at a receiver's operating point (bench.py config3_host).
+// in_syms: XFECFRAME symbols (a demapping chain) or null; in_llr: int8 LLRs (either kind of chain) or null.
+static int chain_decode_host(dvbs2_chain_t* h, const float* in_syms, const int8_t* in_llr, int n_frames, const float* n0, int n0_count,
+                             int max_trials, uint8_t* msg, int32_t* ldpc_ret, int32_t* bch_corr)
+{
+    if (!h) return fail(DVBS2_EINVAL, "null handle");
+    if (h->pending) return fail(DVBS2_EINVAL, "previous call not finished");
+    if (n_frames > h->max_frames) return fail(DVBS2_ESIZE, "n_frames exceeds max_frames");
+    if (n_frames < 0 || max_trials <= 0 || (n_frames && (!msg || (!in_syms && !in_llr)))) return fail(DVBS2_EINVAL, "bad argument");
+    if (in_syms && !h->dm) return fail(DVBS2_EINVAL, "this chain starts at LLRs: use dvbs2_chain_decode_llr");
+    if (in_syms && (!n0 || (n0_count != 1 && n0_count != n_frames))) return fail(DVBS2_EINVAL, "bad argument");
+    if (n_frames == 0) return DVBS2_OK;
+    DeviceGuard guard(h->device);
+    if (!guard.ok) return fail(DVBS2_EDEVICE, "hipSetDevice failed");
+    constexpr int kSl = LdpcDecoderHip::kSlots;
+    LdpcDecoderHip* dec = h->ldpc->dec;
+    const size_t N = (size_t)dec->N(), mf = (size_t)h->max_frames, mb = (size_t)h->msg_bytes;
+    const size_t ns = h->dm ? (size_t)h->dm->dm->n_syms() : 0;
+    const int G = dec->group_size();
+    for (hipStream_t& st : h->hstream) if (!st) HCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    if (!h->hcopy) HCHK(hipStreamCreateWithFlags(&h->hcopy, hipStreamNonBlocking));
+    for (hipEvent_t& ev : h->h_in_ready) if (!ev) HCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    const bool fused = in_syms && dec->fused_demap_supported(); // symbols -> LDS inside the sweep kernel; else demapper launch -> LLR buffer
+    if (in_syms && !h->hd_syms) HCHK(hipMalloc(&h->hd_syms, mf * ns * 8));
+    if (in_syms && !h->hd_n0) HCHK(hipMalloc(&h->hd_n0, mf * 4));
+    if ((in_llr || !fused) && !h->hd_llr) HCHK(hipMalloc(&h->hd_llr, mf * N));
+    if (!h->hd_msg) HCHK(hipMalloc(&h->hd_msg, mf * mb));
+    if (!h->hd_ret) HCHK(hipMalloc(&h->hd_ret, ((mf + G - 1) / G + kSl) * 4));
+    if (!h->hd_corr) HCHK(hipMalloc(&h->hd_corr, mf * 4));
+    const size_t n_groups = ((size_t)n_frames + G - 1) / G;
+    uint8_t* msg_land = host_range_page_locked(msg, (size_t)n_frames * mb) ? msg : nullptr;
+    int32_t* ret_land = host_range_page_locked(ldpc_ret, n_groups * 4) ? ldpc_ret : nullptr;
+    int32_t* corr_land = host_range_page_locked(bch_corr, (size_t)n_frames * 4) ? bch_corr : nullptr;
+    if (!msg_land) { if (!h->p_msg) HCHK(hipHostMalloc(&h->p_msg, mf * mb)); msg_land = h->p_msg; }
+    if (ldpc_ret && !ret_land) { if (!h->p_ret) HCHK(hipHostMalloc(&h->p_ret, ((mf + G - 1) / G + kSl) * 4)); ret_land = h->p_ret; }
+    if (bch_corr && !corr_land) { if (!h->p_corr) HCHK(hipHostMalloc(&h->p_corr, mf * 4)); corr_land = h->p_corr; }
+    const void* in_ptr = in_syms ? (const void*)in_syms : (const void*)in_llr;
+    const size_t in_frame_bytes = in_syms ? ns * 8 : N;
+    const bool in_locked = host_range_page_locked(in_ptr, (size_t)n_frames * in_frame_bytes);
+    // chunk plan: as dvbs2_ldpc_decode (first chunk 512 frames = one launch wave of frame pairs; page-locked input: one large middle chunk
+    // and a small last one; pageable input: chunks of 1024 so that the staged copy of chunk c + 1 runs under the decode of chunk c)
+    const int unit = G % 2 ? 2 * G : G;
+    auto round_unit = [&](int x) { return std::max(unit, (x + unit - 1) / unit * unit); };
+    std::vector<std::pair<int, int>> plan;
+    if (in_locked && n_frames > 1024 && !h->host_chunk) {
+        const int b1 = std::min(round_unit(512), n_frames);
+        const int b2 = std::min(std::max(b1, (n_frames - 512) / unit * unit), n_frames);
+        const int bounds[4] = { 0, b1, b2, n_frames };
+        for (int k = 0; k < 3; k++) if (bounds[k + 1] > bounds[k]) plan.push_back({ bounds[k], bounds[k + 1] - bounds[k] });
+    } else {
+        int first = 512, chunk = std::max(1024, (n_frames + 7) / 8);
+        if (h->host_chunk) first = chunk = h->host_chunk;
+        first = round_unit(first); chunk = round_unit(chunk);
+        for (int f0 = 0; f0 < n_frames;) { const int nf = std::min(f0 ? chunk : first, n_frames - f0); plan.push_back({ f0, nf }); f0 += nf; }
+    }
+    const int n_chunks = (int)plan.size();
+    auto copy_out = [&](int c) -> int {
+        const int f0 = plan[c].first, nf = plan[c].second;
+        hipStream_t st = h->hstream[c % kSl];
+        HCHK(hipMemcpyAsync(msg_land + (size_t)f0 * mb, h->hd_msg + (size_t)f0 * mb, (size_t)nf * mb, hipMemcpyDeviceToHost, st));
+        if (ldpc_ret) HCHK(hipMemcpyAsync(ret_land + f0 / G, h->hd_ret + f0 / G, (size_t)((nf + G - 1) / G) * 4, hipMemcpyDeviceToHost, st));
+        if (bch_corr) HCHK(hipMemcpyAsync(corr_land + f0, h->hd_corr + f0, (size_t)nf * 4, hipMemcpyDeviceToHost, st));
+        return DVBS2_OK;
+    };
+    auto finish = [&](int c) -> int {
+        const int f0 = plan[c].first, nf = plan[c].second;
+        hipStream_t st = h->hstream[c % kSl];
+        const int r = dec->finish(c % kSl);
+        if (r < 0) return fail(DVBS2_EDEVICE, dec->error());
+        if (r > 0) { // the LDPC needed rounds beyond the enqueued ones and rewrote its state: BCH and the copies again
+            if (int rc = chain_bch_range(h, f0, nf, h->hd_msg + (size_t)f0 * mb, h->hd_corr + f0, st)) return rc;
+            if (int rc = copy_out(c)) return rc;
+        }
+        HCHK(hipStreamSynchronize(st));
+        if (msg_land != msg) std::memcpy(msg + (size_t)f0 * mb, msg_land + (size_t)f0 * mb, (size_t)nf * mb);
+        if (ldpc_ret && ret_land != ldpc_ret) std::memcpy(ldpc_ret + f0 / G, ret_land + f0 / G, (size_t)((nf + G - 1) / G) * 4);
+        if (bch_corr && corr_land != bch_corr) std::memcpy(bch_corr + f0, corr_land + f0, (size_t)nf * 4);
+        return DVBS2_OK;
+    };
+    auto run = [&]() -> int {
+        for (int c = 0; c < n_chunks; c++) {
+            if (c >= kSl) if (int rc = finish(c - kSl)) return rc;
+            const int f0 = plan[c].first, nf = plan[c].second;
+            hipStream_t st = h->hstream[c % kSl];
+            hipStream_t cs = in_locked ? h->hcopy : st; // (pageable input: the runtime stages the copy while the caller waits; its own stream)
+            if (in_syms) {
+                HCHK(hipMemcpyAsync(h->hd_syms + (size_t)f0 * ns * 2, in_syms + (size_t)f0 * ns * 2, (size_t)nf * ns * 8, hipMemcpyHostToDevice, cs));
+                if (n0_count > 1) HCHK(hipMemcpyAsync(h->hd_n0 + f0, n0 + f0, (size_t)nf * 4, hipMemcpyHostToDevice, cs));
+                else if (c == 0) HCHK(hipMemcpyAsync(h->hd_n0, n0, 4, hipMemcpyHostToDevice, cs));
+            } else
+                HCHK(hipMemcpyAsync(h->hd_llr + (size_t)f0 * N, in_llr + (size_t)f0 * N, (size_t)nf * N, hipMemcpyHostToDevice, cs));
+            if (cs != st) {
+                HCHK(hipEventRecord(h->h_in_ready[c % kSl], cs));
+                HCHK(hipStreamWaitEvent(st, h->h_in_ready[c % kSl], 0));
+            } else if (in_syms && n0_count == 1 && c > 0 && c < kSl) {
+                // (the single N0 travelled on chunk 0's stream: the first chunks on the other streams wait for it)
+                HCHK(hipStreamWaitEvent(st, h->h_in_ready[0], 0));
+            }
+            if (cs == st && in_syms && n0_count == 1 && c == 0) HCHK(hipEventRecord(h->h_in_ready[0], st));
+            const float* dn0 = n0_count > 1 ? h->hd_n0 + f0 : h->hd_n0;
+            const float* dsy = in_syms ? h->hd_syms + (size_t)f0 * ns * 2 : nullptr;
+            int erc;
+            if (fused) {
+                const DemapFused dm = h->dm->dm->fused(dsy, dn0, n0_count > 1 ? nf : 1);
+                erc = dec->enqueue(nullptr, nf, max_trials, DVBS2_OM_MESSAGE, nullptr, nullptr, h->hd_ret + f0 / G, st, c % kSl, f0, &dm);
+            } else {
+                if (in_syms && h->dm->dm->soft_device(dsy, nf, dn0, n0_count > 1 ? nf : 1, h->hd_llr + (size_t)f0 * N, st)) return fail(DVBS2_EDEVICE, h->dm->dm->error());
+                erc = dec->enqueue(h->hd_llr + (size_t)f0 * N, nf, max_trials, DVBS2_OM_MESSAGE, nullptr, nullptr, h->hd_ret + f0 / G, st, c % kSl, f0, nullptr);
+            }
+            if (erc) return fail(DVBS2_EDEVICE, dec->error());
+            if (int rc = chain_bch_range(h, f0, nf, h->hd_msg + (size_t)f0 * mb, h->hd_corr + f0, st)) return rc;
+            if (int rc = copy_out(c)) return rc;
+        }
+        for (int c = std::max(0, n_chunks - kSl); c < n_chunks; c++) if (int rc = finish(c)) return rc;
+        return DVBS2_OK;
+    };
+    const int rc = run();
+    if (rc != DVBS2_OK) { // nothing of this call stays in flight (copies into the caller's buffers included)
+        const std::string keep = g_err;
+        dec->abort_all();
+        (void)hipStreamSynchronize(h->hcopy);
+        for (hipStream_t st : h->hstream) (void)hipStreamSynchronize(st);
+        g_err = keep;
+    }
+    return rc;
+}
+
+extern "C" {
+
+int dvbs2_chain_decode(dvbs2_chain_t* h, const float* syms, int n_frames, const float* n0, int n0_count, int max_trials,
+                       uint8_t* msg, int32_t* ldpc_ret, int32_t* bch_corr)
+{
+    API_TRY
+    if (n_frames > 0 && !syms) return fail(DVBS2_EINVAL, "bad argument");
+    return chain_decode_host(h, syms, nullptr, n_frames, n0, n0_count, max_trials, msg, ldpc_ret, bch_corr);
+    API_CATCH
+}
+
+int dvbs2_chain_decode_llr(dvbs2_chain_t* h, const int8_t* llr, int n_frames, int max_trials, uint8_t* msg, int32_t* ldpc_ret, int32_t* bch_corr)
+{
+    API_TRY
+    if (n_frames > 0 && !llr) return fail(DVBS2_EINVAL, "bad argument");
+    return chain_decode_host(h, nullptr, llr, n_frames, nullptr, 0, max_trials, msg, ldpc_ret, bch_corr);
+    API_CATCH
 }
 
 } // extern "C"

@@ -162,8 +162,8 @@ LdpcDecoderHip::LdpcDecoderHip(const LdpcTableDesc* table, int out_bits_message,
     if (const char* e = getenv("DVBS2_DENSE")) dense_ = !pr_ && dmax_ == 12 && atoi(e) != 0 && 4 * half_lds_bytes(sched_.N) <= 160 * 1024;
     const bool dense_here = dense_;
     const bool timing_on = getenv("DVBS2_TIMING") != nullptr;
-    solo_ = !pr_ && !dense_ && !hz2_ && dmax_ <= 16 && pol_solo;
-    if (const char* e = getenv("DVBS2_SOLO")) solo_ = !pr_ && !dense_ && !hz2_ && dmax_ <= 16 && atoi(e) != 0;
+    solo_ = !pr_ && !dense_ && !hz2_ && dmax_ <= kSoloMaxDmax && pol_solo;
+    if (const char* e = getenv("DVBS2_SOLO")) solo_ = !pr_ && !dense_ && !hz2_ && dmax_ <= kSoloMaxDmax && atoi(e) != 0;
     if (timing_on) solo_ = false;
     // frame barriers in software (ldpc_kernel.hpp): by rule where no layer has hazards; with hazard layers only for the tables listed in
     // ldpc_policy_soft.inc (measured on two leases, tools/soft_sweep.py)

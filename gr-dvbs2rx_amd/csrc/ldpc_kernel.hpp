@@ -993,7 +993,10 @@ __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, con
         // (degrees above 20 without the low-register form keep the round-2 order -- heads | barrier | publishing | barrier | walk |
         // barrier | completion | barrier --: reading entry 0 inside the first phase costs the degree class 28 sixteen more spilled
         // registers and table B10 7 %)
-        constexpr bool kTwoBarrier = LR || DEG <= 20;
+#ifndef DVBS2_TWO_BARRIER_V2P
+#define DVBS2_TWO_BARRIER_V2P 0 // experiments (round 6): the two-barrier order also in the packed hazard nodes of degree > 20
+#endif
+        constexpr bool kTwoBarrier = LR || DEG <= 20 || (V2P && DVBS2_TWO_BARRIER_V2P != 0);
         const bool orig0 = work && (kTwoBarrier ? jj + block < kM : jj < block); // entry 0 still holds its value from before the layer (every head is one: block <= 128)
         if (orig0) {
             const int L0 = kEarlyPair ? Lh01[0] : lds_rdx<TC>(ad[0]);
@@ -1373,7 +1376,7 @@ __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, con
         // same wavefront (LDS operations of a wave execute in program order)
         if ((start >> 6) != ((start + 2 * block - 1) >> 6)) lds_barrier();
     }
-    if (!lane_chain || !(LR || DEG <= 20)) lds_barrier(); // (uniform; the last phase of a two-barrier lane chain and the outputs below touch different bits)
+    if (!lane_chain || !(LR || DEG <= 20 || (V2P && DVBS2_TWO_BARRIER_V2P != 0))) lds_barrier(); // (uniform; the last phase of a two-barrier lane chain and the outputs below touch different bits)
     DVBS2_PH(6); // ordered steps of the block scheme + closing barrier / completion of the chain rows
     if constexpr (V2P) {
         // LAST PHASE, packed: the ordered entries enter the packed domain as pairs [inp << 8] (what they read in their step is final), the
@@ -2101,11 +2104,11 @@ struct LdpcLaunch {
 };
 template <int DMAX> hipError_t ldpc_variant_prepare(size_t pair_lds_bytes, size_t solo_lds_bytes);
 template <int DMAX> void ldpc_variant_launch(const LdpcLaunch& a);
-#ifdef DVBS2_SOLO_MAX_DMAX
-template <int DMAX> constexpr bool kSoloBuilt = (DMAX <= DVBS2_SOLO_MAX_DMAX); // experiments: one-frame workgroups for the low-register builds
-#else
-template <int DMAX> constexpr bool kSoloBuilt = (DMAX <= 16);
+#ifndef DVBS2_SOLO_MAX_DMAX
+#define DVBS2_SOLO_MAX_DMAX 16 // (experiments: one-frame workgroups -- 128 VGPRs -- for higher degree classes; round 6 bound, notes/r06_experiments.md)
 #endif
+constexpr int kSoloMaxDmax = DVBS2_SOLO_MAX_DMAX;
+template <int DMAX> constexpr bool kSoloBuilt = (DMAX <= kSoloMaxDmax);
 // plain builds with the packed chain node: measured SLOWER than the plain build's own lane chain (B4 107.8 k vs 109.8 k, B5 57.9 k vs
 // 62.2 k frames/s) although its ordered steps cost a third -- the node's register state hurts the rest of the kernel. Not built.
 template <int DMAX> constexpr bool kHz2Built = (DMAX >= 12);

@@ -392,6 +392,34 @@ class FecChain:
     def set_descramble(self, enable=True):
         check(lib.dvbs2_chain_set_descramble(self._h, int(bool(enable))))
 
+    def work(self, syms, n0, want_ret=True):
+        """HOST buffers (dvbs2_chain_decode): syms complex64 [n_frames, n_syms] (or float32 [n_frames, 2 n_syms]), n0 scalar or
+        one float per frame. Returns (msg uint8 [n_frames, msg_bytes], ldpc_ret int32 per group, bch_corr int32 per frame)."""
+        syms = np.ascontiguousarray(syms)
+        n_frames = syms.shape[0]
+        n0 = np.ascontiguousarray(np.atleast_1d(np.asarray(n0, np.float32)))
+        msg = np.empty((n_frames, self.msg_bytes), np.uint8)
+        ret = np.empty(((n_frames + self.group_size - 1) // self.group_size,), np.int32)
+        corr = np.empty((n_frames,), np.int32)
+        check(lib.dvbs2_chain_decode(self._h, syms.ctypes.data, n_frames, n0.ctypes.data, int(n0.size), self.max_trials,
+                                     msg.ctypes.data, ret.ctypes.data if want_ret else None, corr.ctypes.data if want_ret else None))
+        return msg, ret, corr
+
+    def work_llr(self, llr, want_ret=True):
+        """HOST buffers (dvbs2_chain_decode_llr): llr int8 [n_frames, N]."""
+        llr = np.ascontiguousarray(llr, np.int8)
+        n_frames = llr.shape[0]
+        msg = np.empty((n_frames, self.msg_bytes), np.uint8)
+        ret = np.empty(((n_frames + self.group_size - 1) // self.group_size,), np.int32)
+        corr = np.empty((n_frames,), np.int32)
+        check(lib.dvbs2_chain_decode_llr(self._h, llr.ctypes.data, n_frames, self.max_trials, msg.ctypes.data,
+                                         ret.ctypes.data if want_ret else None, corr.ctypes.data if want_ret else None))
+        return msg, ret, corr
+
+    def work_host_ptr(self, syms_ptr, n_frames, n0_ptr, n0_count, msg_ptr, ret_ptr=0, corr_ptr=0):
+        """dvbs2_chain_decode on raw HOST addresses (page-locked buffers of the caller: bench.py)."""
+        check(lib.dvbs2_chain_decode(self._h, syms_ptr, n_frames, n0_ptr, n0_count, self.max_trials, msg_ptr, ret_ptr or None, corr_ptr or None))
+
     def work_device(self, d_syms, n_frames, d_n0, n0_count, d_msg, d_ldpc_ret=0, d_bch_corr=0, stream=0):
         check(lib.dvbs2_chain_decode_device(self._h, d_syms, n_frames, d_n0, n0_count, self.max_trials, d_msg,
                                             d_ldpc_ret or None, d_bch_corr or None, stream or None))

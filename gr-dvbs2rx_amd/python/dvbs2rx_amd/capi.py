@@ -63,6 +63,7 @@ SYMBOLS = {
     "dvbs2_ldpc_kernel_name": (C.c_char_p, [_vp]),
     "dvbs2_ldpc_fallback_rounds": (_i, [_vp]),
     "dvbs2_measure_host_copy": (_i, [_i, C.c_size_t, _i, _i, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "dvbs2_measure_shader_clock": (_i, [_i, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "dvbs2_bch_create": (_i, [C.POINTER(_vp), _i, _i, _i, _i, _i]),
     "dvbs2_bch_create_raw": (_i, [C.POINTER(_vp), _i, C.c_uint32, _i, _i, _i, _i]),
     "dvbs2_bch_destroy": (None, [_vp]),
@@ -107,6 +108,8 @@ SYMBOLS = {
     "dvbs2_chain_enqueue_device": (_i, [_vp, _vp, _i, _vp, _i, _i, _vp, _vp, _vp, _vp]),
     "dvbs2_chain_enqueue_llr_device": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
     "dvbs2_chain_finish": (_i, [_vp]),
+    "dvbs2_chain_decode": (_i, [_vp, _vp, _i, _vp, _i, _i, _vp, _vp, _vp]),
+    "dvbs2_chain_decode_llr": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp]),
     "dvbs2_chain_ldpc_profile": (_i, [_vp, _i, C.POINTER(C.c_double), _ip]),
     "dvbs2_chain_ldpc_kernel_name": (C.c_char_p, [_vp]),
 }

@@ -142,6 +142,10 @@ int dvbs2_ldpc_fallback_rounds(const dvbs2_ldpc_t* h);
  * does to a caller's buffer), 2 = pageable malloc. Beside the host-entry rates of bench.py (config2_host): is the link or the
  * pipeline what limits dvbs2_ldpc_decode? (reference call site that hands over host buffers: lib/ldpc_decoder_bb_impl.cc:406-449) */
 int dvbs2_measure_host_copy(int device, size_t bytes, int n_streams, int kind, double* h2d_gbs, double* d2h_gbs);
+/* Diagnostics. The shader clock of this device under VALU load, GHz: every SIMD runs dependent adds for ~1 ms; the s_memtime delta (what the
+ * cycle stamps and the SQ cycle counters count in) over the s_memrealtime delta (100 MHz) of one workgroup. bench.py converts the SQ pass's
+ * cycle counts with it instead of assuming the nominal 2.4 GHz (roofline.limiter). kernel_ms (nullable): duration of the probe. */
+int dvbs2_measure_shader_clock(int device, double* ghz, double* kernel_ms);
 /* which sweep kernel the handle launches, as rocprofv3 names it: "ldpc_layered_kernel<DMAX>" or
  * "ldpc_layered_pr_kernel" (parity LLRs kept in registers / message records; chosen per table, identical results) */
 const char* dvbs2_ldpc_kernel_name(const dvbs2_ldpc_t* h);
@@ -248,6 +252,21 @@ int dvbs2_chain_enqueue_device(dvbs2_chain_t* h, const float* d_syms, int n_fram
 int dvbs2_chain_enqueue_llr_device(dvbs2_chain_t* h, const int8_t* d_llr, int n_frames, int max_trials, uint8_t* d_msg,
                                    int32_t* d_ldpc_ret, int32_t* d_bch_corr, void* stream);
 int dvbs2_chain_finish(dvbs2_chain_t* h);
+/* The fused chain from HOST buffers (the "fused entry, symbols -> message bytes" of SURVEY 8(b)): what the three blocks do with the item
+ * buffers GNU Radio hands them, in one call -- xfecframe_demapper_cb_impl::general_work (reference lib/xfecframe_demapper_cb_impl.cc:101-186)
+ * -> ldpc_decoder_bb_impl::general_work (lib/ldpc_decoder_bb_impl.cc:394-455) -> bch_decoder_bb_impl::general_work
+ * (lib/bch_decoder_bb_impl.cc:84-117), wired as in apps/dvbs2-rx:853-863.
+ * syms      n_frames * n_syms complex symbols as interleaved (re, im) floats (HOST), n0 / n0_count as for dvbs2_demap_soft (HOST)
+ * msg       n_frames * bch_k/8 bytes (HOST); ldpc_ret (nullable): one int32 per LDPC group; bch_corr (nullable): one int32 per frame
+ * The call is cut into chunks of whole LDPC groups over four streams (the plan of dvbs2_ldpc_decode): the input copy of chunk c + 1 and
+ * the output copy of chunk c - 1 run under the kernels of chunk c. Buffers that lie inside ONE page-locked allocation / registration
+ * (dvbs2_host_register, hipHostMalloc) are addressed by the copy engine directly; pageable ones go through staging (slower, never wrong).
+ * An 8PSK normal frame is 172.8 KB of symbols: the host link (~57 GB/s measured) bounds this entry near 320 k frames/s. */
+int dvbs2_chain_decode(dvbs2_chain_t* h, const float* syms, int n_frames, const float* n0, int n0_count, int max_trials,
+                       uint8_t* msg, int32_t* ldpc_ret, int32_t* bch_corr);
+/* the same from int8 LLRs on the host (chains of either kind): ldpc_decoder_bb -> bch_decoder_bb */
+int dvbs2_chain_decode_llr(dvbs2_chain_t* h, const int8_t* llr, int n_frames, int max_trials, uint8_t* msg, int32_t* ldpc_ret,
+                           int32_t* bch_corr);
 /* dvbs2_ldpc_profile / dvbs2_ldpc_kernel_name of the chain's LDPC stage (the dominant kernel) */
 int dvbs2_chain_ldpc_profile(dvbs2_chain_t* h, int enable, double* total_ms, int* launches);
 const char* dvbs2_chain_ldpc_kernel_name(const dvbs2_chain_t* h);

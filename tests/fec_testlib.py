@@ -177,6 +177,24 @@ def ref_ldpc_decode(table, llr, impl, trials):
     return out, rets
 
 
+def cpu_ldpc_decode_ragged(table, llr, G, trials):
+    """Any number of frames: whole groups of G through the genuine reference when it serves that G (32: AVX2), the trailing partial
+    group -- a group of its own, like the HIP path treats it -- through the scalar restatement (which takes any group size)."""
+    nf = llr.shape[0]
+    full = nf - nf % G
+    outs, rets = [], []
+    if full:
+        if ref_ldpc() is not None and G == 32:
+            o, r = ref_ldpc_decode(table, llr[:full], 0, trials)
+        else:
+            o, r = oracle_ldpc_decode(table, llr[:full], G, trials)
+        outs.append(o); rets += list(r)
+    if nf > full:
+        o, r = oracle_ldpc_decode(table, llr[full:], nf - full, trials)
+        outs.append(o); rets += list(r)
+    return np.concatenate(outs), rets
+
+
 def ref_ldpc_decode_parallel(table, llr, impl, trials, procs=None):
     """Genuine reference on a WHOLE batch: worker processes (tools/cpu_ref_decode_worker.py), each decoding a contiguous
     range of groups of a shared .npy file in /dev/shm. Returns (decoded llr, list of return values per group), identical

@@ -1,9 +1,10 @@
 // tests/host_blocks_main.cpp -- drives the C++ host mirror (gr-dvbs2rx_amd/host/dvbs2rx_hip_blocks.h) the way a
 // GNU Radio scheduler thread would: forecast() + general_work() on byte streams read from files written by
 // tests/test_host_blocks.py, which then compares the output streams with the CPU oracle.
-//   usage: host_blocks_main <ldpc|bch|bbdh|demap|loop> <in file> <out file> <framesize> <rate name> <arg>
+//   usage: host_blocks_main <ldpc|bch|bbdh|demap|loop|chain> <in file> <out file> <framesize> <rate name> <arg>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <fstream>
 #include <iostream>
 #include <iterator>
@@ -83,6 +84,34 @@ int main(int argc, char** argv)
                     std::printf("found %d snr_lin %.6f\n", found, std::pow(10.0, dm->get_snr() / 10.0));
                 }
             }
+        } else if (kind == "chain") {
+            // the three blocks one after the other on HOST buffers (what GNU Radio's scheduler does, apps/dvbs2-rx:853-863) against ONE call
+            // of the fused host-pointer entry dvbs2_chain_decode on the same symbols; `arg` = constellation, fixed N0 = 1 / 7.0
+            const dvb_constellation_t mod = (dvb_constellation_t)arg;
+            auto dm = xfecframe_demapper_cb::make(fs, rate, mod, 256);
+            auto ld = ldpc_decoder_bb::make(STANDARD_DVBS2, fs, rate, mod, OM_MESSAGE, INFO_OFF, 25, 0, 32, 256);
+            auto bc = bch_decoder_bb::make(STANDARD_DVBS2, fs, rate, OM_MESSAGE);
+            dm->set_snr_lin(7.0f);
+            gr_vector_int r1(1);
+            dm->forecast(dm->output_multiple(), r1);
+            const int n_frames = (int)(in.size() / ((size_t)r1[0] * 8));
+            std::vector<char> llr((size_t)n_frames * dm->output_multiple()), bits((size_t)n_frames * (ld->output_multiple() / 32)); // (the LDPC block's granule is one group of 32 frames: n_frames must be a multiple of it)
+            out.resize((size_t)n_frames * bc->output_multiple());
+            int c = 0;
+            { gr_vector_void_star o1(1, llr.data()); dm->general_work((int)llr.size(), ninput, ii, o1, &c); consumed = c; }
+            { gr_vector_const_void_star i2(1, llr.data()); gr_vector_void_star o2(1, bits.data()); ld->general_work((int)bits.size(), ninput, i2, o2, &c); }
+            { gr_vector_const_void_star i3(1, bits.data()); oo[0] = out.data(); produced = bc->general_work((int)out.size(), ninput, i3, oo, &c); }
+            dvbs2_chain_t* ch = nullptr;
+            if (dvbs2_chain_create(&ch, STANDARD_DVBS2, fs, rate, mod, 32, n_frames, 0) != DVBS2_OK) { std::printf("chain create: %s\n", dvbs2_last_error()); return 5; }
+            std::vector<unsigned char> fused(out.size());
+            std::vector<int32_t> ret((n_frames + 31) / 32), corr(n_frames);
+            const float n0 = 1.0f / 7.0f;
+            if (dvbs2_chain_decode(ch, reinterpret_cast<const float*>(in.data()), n_frames, &n0, 1, 25, fused.data(), ret.data(), corr.data()) != DVBS2_OK) { std::printf("chain decode: %s\n", dvbs2_last_error()); return 5; }
+            dvbs2_chain_destroy(ch);
+            int bad = 0;
+            for (int f = 0; f < n_frames; f++) bad += corr[f] < 0;
+            std::printf("frames %d fused_equals_blocks %d bch_failures %d block_errors %llu\n", n_frames, (int)(std::memcmp(fused.data(), out.data(), out.size()) == 0), bad,
+                        (unsigned long long)bc->get_error_count());
         } else {
             auto b = xfecframe_demapper_cb::make(fs, rate, (dvb_constellation_t)arg);
             int nout = b->output_multiple() * 2;

@@ -385,6 +385,102 @@ def test_chain_from_llrs(rate):
     chain.close()
 
 
+# ------------------------------------------------------------------ host-pointer form of the fused chain (dvbs2_chain_decode)
+def _chain_symbols(framesize, rate, constellation, nf, seed, es_n0_db, order=0):
+    """Mapped BCH o LDPC codewords + AWGN (a few frames are pure noise), N0, and what was sent."""
+    fi = get_fec_info(capi.STANDARD_DVBS2, framesize, rate)
+    ob, _ = bch_pair(framesize, rate)
+    rng = np.random.default_rng(seed)
+    msg = rng.integers(0, 256, (nf, fi["bch_k"] // 8), dtype=np.uint8)
+    cw = T.ldpc_encode(fi["table"], np.unpackbits(ob.encode_bytes(msg), axis=1))
+    if constellation == capi.MOD_QPSK:
+        syms = ((1 - 2.0 * cw[:, 0::2]) + 1j * (1 - 2.0 * cw[:, 1::2])) * np.sqrt(0.5)
+    else:
+        rows = cw.shape[1] // 3  # bit k of symbol s is codeword bit ra_k + s (the block's column de-interleaver, lib/xfecframe_demapper_cb_impl.cc:50-69,162-176)
+        ra = {0: (0, rows, 2 * rows), 1: (2 * rows, rows, 0), 2: (rows, 0, 2 * rows)}[order]
+        syms = T.map_8psk(np.stack([cw[:, a:a + rows] for a in ra], axis=-1))
+    n0 = np.float32(10 ** (-es_n0_db / 10))
+    noise = np.sqrt(n0 / 2) * (rng.normal(size=syms.shape) + 1j * rng.normal(size=syms.shape))
+    rx = (syms + noise).astype(np.complex64)
+    for f in range(3, nf, 17):
+        rx[f] = (noise[f] * 3).astype(np.complex64)  # hopeless frames: their groups run to the cap, the BCH sees garbage
+    return fi, ob, rx, n0, msg
+
+
+@pytest.mark.parametrize("framesize,rate,constellation,nf,chunk,es_n0_db,order", [
+    (capi.FECFRAME_NORMAL, "C3_4", capi.MOD_8PSK, 70, 32, 8.5, 0),    # demapper fused into the sweep load; chunks 32 + 32 + 6
+    (capi.FECFRAME_SHORT, "C1_4", capi.MOD_QPSK, 200, 32, 0.5, 0),    # parity-in-records sweep kernel: demapper launch per chunk; 7 chunks > 4 slots
+    (capi.FECFRAME_SHORT, "C3_5", capi.MOD_8PSK, 97, 0, 7.0, 1),      # the measured plan (one chunk here), column order 210
+])
+def test_chain_host_entry(framesize, rate, constellation, nf, chunk, es_n0_db, order, monkeypatch):
+    """dvbs2_chain_decode (HOST symbols -> HOST message bytes, chunked over four streams) against the CPU chain -- demapper
+    restatement -> genuine LDPC reference -> BCH codec --, with pageable and with page-locked caller buffers, one N0 and one per frame;
+    and against the device-pointer entry."""
+    import torch
+    if chunk:
+        monkeypatch.setenv("DVBS2_HOST_CHUNK", str(chunk))
+    cap, G = 25, 32
+    fi, ob, rx, n0, sent = _chain_symbols(framesize, rate, constellation, nf, 1234 + nf, es_n0_db, order)
+    llr = T.oracle_demap(rx, n0, 4 if constellation == capi.MOD_QPSK else 8, order)  # (the checker takes the constellation SIZE)
+    dec_llr, wret = T.cpu_ldpc_decode_ragged(fi["table"], llr, G, cap)
+    want_msg, want_corr = ob.decode_bytes(T.pack_bits(dec_llr, fi["bch_n"]))
+    assert (want_corr >= 0).sum() > nf // 2 and (want_corr < 0).any()
+    good = want_corr >= 0
+    assert np.array_equal(want_msg[good], sent[good])
+    chain = FecChain(framesize=framesize, rate=rate, constellation=constellation, group_size=G, max_frames=nf + 7, max_trials=cap)
+    # pageable caller buffers, one N0
+    msg, ret, corr = chain.work(rx, n0)
+    assert ret.tolist() == wret and corr.tolist() == want_corr.tolist() and np.array_equal(msg, want_msg)
+    # one N0 per frame (the block before the first llr_pdu, lib/xfecframe_demapper_cb_impl.cc:128-149)
+    msg2, ret2, corr2 = chain.work(rx, np.full(nf, n0, np.float32))
+    assert ret2.tolist() == wret and corr2.tolist() == want_corr.tolist() and np.array_equal(msg2, want_msg)
+    # page-locked caller buffers (copy engine addresses them directly), outputs optional
+    hin = torch.from_numpy(rx.view(np.float32).reshape(nf, -1)).pin_memory()
+    hn0 = torch.tensor([float(n0)], dtype=torch.float32).pin_memory()
+    hmsg = torch.zeros((nf, chain.msg_bytes), dtype=torch.uint8).pin_memory()
+    hcorr = torch.zeros(nf, dtype=torch.int32).pin_memory()
+    assert capi.lib.dvbs2_host_is_page_locked(hin.data_ptr(), hin.numel() * 4) == 1
+    chain.work_host_ptr(hin.data_ptr(), nf, hn0.data_ptr(), 1, hmsg.data_ptr(), 0, hcorr.data_ptr())
+    assert np.array_equal(hmsg.numpy(), want_msg) and hcorr.numpy().tolist() == want_corr.tolist()
+    # a shorter call on the same handle, then the device-pointer entry: same bytes
+    dec33, wret33 = T.cpu_ldpc_decode_ragged(fi["table"], llr[:33], G, cap)  # (frame 32 is now a group of its own)
+    want33, corr33 = ob.decode_bytes(T.pack_bits(dec33, fi["bch_n"]))
+    msg3, ret3, corr3 = chain.work(rx[:33], n0)
+    assert np.array_equal(msg3, want33) and ret3.tolist() == wret33 and corr3.tolist() == corr33.tolist()
+    d_syms = hin.cuda()
+    d_n0 = hn0.cuda()
+    d_msg = torch.empty((nf, chain.msg_bytes), dtype=torch.uint8, device="cuda")
+    chain.work_device(d_syms.data_ptr(), nf, d_n0.data_ptr(), 1, d_msg.data_ptr(), 0, 0, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(d_msg.cpu().numpy(), want_msg)
+    # bad arguments leave the handle usable
+    assert capi.lib.dvbs2_chain_decode(chain._h, None, 4, hn0.data_ptr(), 1, cap, hmsg.data_ptr(), None, None) == capi.EINVAL
+    assert capi.lib.dvbs2_chain_decode(chain._h, hin.data_ptr(), nf + 8, hn0.data_ptr(), 1, cap, hmsg.data_ptr(), None, None) == capi.ESIZE
+    assert capi.lib.dvbs2_chain_decode(chain._h, hin.data_ptr(), nf, hn0.data_ptr(), 2, cap, hmsg.data_ptr(), None, None) == capi.EINVAL
+    msg4, _, _ = chain.work(rx, n0, want_ret=False)
+    assert np.array_equal(msg4, want_msg)
+    chain.close()
+
+
+def test_chain_host_entry_from_llrs(monkeypatch):
+    """dvbs2_chain_decode_llr (HOST LLRs -> HOST message bytes) on 9/10 normal (BASELINE config 5's code), three chunks."""
+    monkeypatch.setenv("DVBS2_HOST_CHUNK", "32")
+    rate, nf, G, cap = "C9_10", 72, 32, 20
+    fi = get_fec_info(capi.STANDARD_DVBS2, capi.FECFRAME_NORMAL, rate)
+    ob, _ = bch_pair(capi.FECFRAME_NORMAL, rate)
+    rng = np.random.default_rng(92)
+    sent = rng.integers(0, 256, (nf, fi["bch_k"] // 8), dtype=np.uint8)
+    cw = T.ldpc_encode(fi["table"], np.unpackbits(ob.encode_bytes(sent), axis=1))
+    llr = np.clip(np.rint((1.0 - 2.0 * cw) * 9.0 + rng.normal(0, 3.3, cw.shape)), -128, 127).astype(np.int8)
+    llr[40] = T.llr_noise(1, cw.shape[1], 5)[0]
+    want_msg, want_corr, wret, _ = T.chain_expect(fi["table"], fi["bch_n"], fi["bch_t"], capi.FECFRAME_NORMAL, llr, cap)
+    chain = FecChain(rate=rate, group_size=G, max_frames=nf, max_trials=cap, from_llr=True)
+    msg, ret, corr = chain.work_llr(llr)
+    assert ret.tolist() == list(wret) and corr.tolist() == list(want_corr) and np.array_equal(msg, want_msg)
+    assert capi.lib.dvbs2_chain_decode(chain._h, llr.ctypes.data, nf, None, 0, cap, msg.ctypes.data, None, None) == capi.EINVAL  # no demapper in this chain
+    chain.close()
+
+
 # ------------------------------------------------------------------ BASELINE configs 3 and 5 at full size, the benchmark's own input
 @pytest.mark.parametrize("config", ["config3", "config5", "config5_s2x"])
 def test_full_batch_chains_vs_reference(config):

@@ -104,3 +104,27 @@ def test_demapper_llr_pdu_feedback_loop(exe, tmp_path):
     assert abs(ref - 1 / (2 * 0.55 ** 2)) / ref < 0.05  # decoded frames => the true SNR
     llr1 = T.oracle_demap(syms[32:], np.float32(1.0) / np.float32(got), 4)
     assert np.mean(out[32:] != llr1) < 1e-3 and np.abs(out[32:].astype(int) - llr1).max() <= 1
+
+
+def test_three_blocks_equal_the_fused_host_entry(exe, tmp_path):
+    """C++ only, through the C ABI: xfecframe_demapper_cb -> ldpc_decoder_bb -> bch_decoder_bb (the mirror's general_work on host
+    buffers, one block after the other) give the bytes of ONE dvbs2_chain_decode call on the same symbols; both equal the CPU chain."""
+    framesize, rate, nf = capi.FECFRAME_SHORT, "C1_2", 96  # (whole groups of 32: the LDPC block's granule)
+    fi = get_fec_info(capi.STANDARD_DVBS2, framesize, rate)
+    m, prim = T.BCH_FIELDS[framesize]
+    ob = T.OracleBch(m, prim, fi["bch_t"], fi["bch_n"])
+    rng = np.random.default_rng(77)
+    sent = rng.integers(0, 256, (nf, fi["bch_k"] // 8), dtype=np.uint8)
+    cw = T.ldpc_encode(fi["table"], np.unpackbits(ob.encode_bytes(sent), axis=1))
+    pts = ((1 - 2.0 * cw[:, 0::2]) + 1j * (1 - 2.0 * cw[:, 1::2])) * np.sqrt(0.5)
+    syms = (pts + np.sqrt(1 / 14.0) * (rng.normal(size=pts.shape) + 1j * rng.normal(size=pts.shape))).astype(np.complex64)  # Es/N0 = 7
+    syms[11] *= 0.05  # one frame below the noise
+    out, log = run(exe, tmp_path, "chain", syms, framesize, rate, capi.MOD_QPSK)
+    llr = T.oracle_demap(syms, np.float32(1.0) / np.float32(7.0), 4)
+    dec = np.concatenate([T.oracle_ldpc_decode(fi["table"], llr[a:a + 32], 32, 25)[0] for a in range(0, nf, 32)])
+    want, wcorr = ob.decode_bytes(T.pack_bits(dec, fi["bch_n"]))
+    assert f"frames {nf} fused_equals_blocks 1" in log, log
+    assert f"bch_failures {int((wcorr < 0).sum())} block_errors {int((wcorr < 0).sum())}" in log, log
+    assert np.array_equal(out.reshape(nf, -1), want)
+    good = wcorr >= 0
+    assert good.sum() >= nf - 2 and np.array_equal(want[good], sent[good])
