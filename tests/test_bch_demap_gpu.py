@@ -465,7 +465,7 @@ def test_chain_host_entry(framesize, rate, constellation, nf, chunk, es_n0_db, o
 def test_chain_host_entry_from_llrs(monkeypatch):
     """dvbs2_chain_decode_llr (HOST LLRs -> HOST message bytes) on 9/10 normal (BASELINE config 5's code), three chunks."""
     monkeypatch.setenv("DVBS2_HOST_CHUNK", "32")
-    rate, nf, G, cap = "C9_10", 72, 32, 20
+    rate, nf, G, cap = "C9_10", 96, 32, 20  # (whole reference batches: the CPU chain runs the genuine AVX2 decoder)
     fi = get_fec_info(capi.STANDARD_DVBS2, capi.FECFRAME_NORMAL, rate)
     ob, _ = bch_pair(capi.FECFRAME_NORMAL, rate)
     rng = np.random.default_rng(92)
