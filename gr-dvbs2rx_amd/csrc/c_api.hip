@@ -492,6 +492,27 @@ int dvbs2_measure_shader_clock(int device, double* ghz, double* kernel_ms)
     API_CATCH
 }
 
+int dvbs2_debug_cu_slot_table(int device, int device_key, unsigned long long* table_address, int* nonzero_words)
+{
+    API_TRY
+    if (!table_address) return fail(DVBS2_EINVAL, "bad argument");
+    DeviceGuard guard(device);
+    if (!guard.ok) return fail(DVBS2_EDEVICE, "hipSetDevice failed");
+    std::string e;
+    int* t = cu_slot_table(device_key, &e);
+    if (!t) return fail(DVBS2_EDEVICE, e);
+    *table_address = (unsigned long long)(uintptr_t)t;
+    if (nonzero_words) {
+        std::vector<int> hv(kCuSlotWords);
+        HCHK(hipMemcpy(hv.data(), t, hv.size() * 4, hipMemcpyDeviceToHost));
+        int nz = 0;
+        for (int v : hv) nz += v != 0;
+        *nonzero_words = nz;
+    }
+    return DVBS2_OK;
+    API_CATCH
+}
+
 int dvbs2_ldpc_profile(dvbs2_ldpc_t* h, int enable, double* total_ms, int* launches)
 {
     if (!h) return fail(DVBS2_EINVAL, "null handle");

@@ -8,6 +8,10 @@
 
 namespace dvbs2 {
 
+// per-CU wave-pattern counters of the one-frame sweep kernels: one device array per device key (ldpc_hip.hip)
+int* cu_slot_table(int device_key, std::string* err);
+constexpr int kCuSlotWords = 16 * 8 * 2 * 16;
+
 class LdpcDecoderHip {
 public:
     // group_size G: frames [G*g, G*g+G) share one iteration count, exactly like one SIMD batch of the

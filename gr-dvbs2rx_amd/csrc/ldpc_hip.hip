@@ -89,18 +89,38 @@ __global__ void ldpc_finalize_kernel(const uint8_t* state, uint8_t* bits, int8_t
     if (bits && b < out_bytes) bits[(size_t)f * out_bytes + b] = (uint8_t)((neg_bits4(v.x) << 4) | neg_bits4(v.y));
 }
 
+// The per-CU pattern counters of the one-frame builds, ONE array per device for all handles (see the constructor): keyed by the device id,
+// allocated on the CURRENT device and zeroed before its pointer is published, never freed (the counts survive the handles; they are not
+// valid across hipDeviceReset()). A function of its own so that the table can be exercised with device keys a one-GPU box does not have
+// (dvbs2_debug_cu_slot_table, tests/test_ldpc_gpu.py::test_cu_slot_table_is_per_device).
+int* cu_slot_table(int device_key, std::string* err)
+{
+    static std::mutex mu;
+    static std::vector<std::pair<int, int*>> per_device;
+    std::lock_guard<std::mutex> lk(mu);
+    for (const auto& e : per_device) if (e.first == device_key) return e.second;
+    int* slots = nullptr;
+    if (hipMalloc(&slots, kCuSlots * 4) != hipSuccess) { if (err) *err = "hipMalloc of the per-CU counters failed"; return nullptr; }
+    if (hipMemset(slots, 0, kCuSlots * 4) != hipSuccess) { (void)hipFree(slots); if (err) *err = "hipMemset of the per-CU counters failed"; return nullptr; }
+    per_device.push_back({ device_key, slots });
+    return slots;
+}
+
 LdpcDecoderHip::LdpcDecoderHip(const LdpcTableDesc* table, int out_bits_message, int group_size, int max_frames, int device)
     : out_bits_message_(out_bits_message), G_(group_size), max_frames_(max_frames), device_(device)
 {
     if (!compile_ldpc_schedule(table, &sched_)) { err_ = "unknown or inconsistent LDPC table"; return; }
     if (G_ < 1 || max_frames_ < 1 || max_frames_ > 65535) { err_ = "bad group_size/max_frames (max_frames 1..65535: frames are one launch dimension)"; return; }
     if (out_bits_message_ <= 0 || out_bits_message_ > sched_.N || out_bits_message_ % 8) { err_ = "bad message length"; return; }
-    if (getenv("DVBS2_EXP_NOHAZ")) { // timing-only bound (wrong results): every layer runs as a regular layer
+#ifdef DVBS2_EXPERIMENTS // timing-only bounds that give WRONG results: compiled into experiment builds only (tools/build_variant.sh <name> -DDVBS2_EXPERIMENTS),
+                         // never into the library that ships -- a stray environment variable cannot corrupt a deployment's output
+    if (getenv("DVBS2_EXP_NOHAZ")) { // every layer runs as a regular layer
         for (LdpcLayer& L : sched_.layers) { L.block = 360; L.n_conflict = 0; }
         sched_.conflict_layers = 0;
     }
-    if (getenv("DVBS2_EXP_NOSYNC")) // timing-only bound (wrong results): no barrier in front of a regular layer
+    if (getenv("DVBS2_EXP_NOSYNC")) // no barrier in front of a regular layer
         for (LdpcLayer& L : sched_.layers) if (L.block >= 360) L.sync_before = 0;
+#endif
     int degmax = 0, degmin = 1000;
     for (const LdpcLayer& L : sched_.layers) { degmax = std::max(degmax, L.cnt + 2); degmin = std::min(degmin, L.cnt + 2); }
     if (degmax > 32) { err_ = "check degree > 32 unsupported"; return; }
@@ -196,7 +216,7 @@ LdpcDecoderHip::LdpcDecoderHip(const LdpcTableDesc* table, int out_bits_message,
         int order[64];
         for (int k = 0; k < L.cnt + 2; k++) order[k] = k;
         uint32_t chain = 0;
-        if (!dense_here && L.block <= lane_chain_max && nc_code == 2 && L.n_conflict == 2 && (L.cnt + 2 <= kLaneChainMaxDeg || dmax_ >= kLowRegMinDmax || (packed_intent && v2p_class(dmax_) && L.cnt + 2 <= kLaneChainMaxDegV2p)) &&
+        if (!dense_here && L.block <= lane_chain_max && nc_code == 2 && L.n_conflict == 2 && (L.cnt + 2 <= kLaneChainMaxDeg || (packed_intent && v2p_class(dmax_) && L.cnt + 2 <= kLaneChainMaxDegV2p)) &&
             (sched_.N / 360) * kSvWords >= lane_chain_words(L.block)) {
             const LdpcEntry& a = sched_.entries[L.entry_off], & b = sched_.entries[L.entry_off + 1];
             if (a.base == b.base) {
@@ -211,7 +231,7 @@ LdpcDecoderHip::LdpcDecoderHip(const LdpcTableDesc* table, int out_bits_message,
         // (the degree class 32 without the heavy-hazard paths walks the near pair as a lane chain inside the outer blocks -- the
         // two-level lane chain of check_node_hazard: the pair additionally has to be oriented like a single-pair chain, bit 12)
         // (not in the 80-VGPR build -- same rule as where dense_ is set below --: the chain's state does not fit there, 76 -> 349 spilled registers)
-        const bool tlc_build = tlc_class(dmax_) && !hz2_ && !pr_ && !dense_here && (!soft_bar_ || DVBS2_TLC_SOFT); // (kTlc<DMAX, HZ2> && !SOFT && MINW == 1 in the kernel)
+        const bool tlc_build = tlc_class(dmax_) && !hz2_ && !pr_ && !dense_here && !soft_bar_; // (kTlc<DMAX, HZ2> && !SOFT && MINW == 1 in the kernel)
         if (tlc_build && two_level_on && L.block < 360 && L.block <= lane_chain_max && (nc_code == 4 || nc_code == 8) &&
             (sched_.N / 360) * kSvWords >= lane_chain_words(L.block)) {
             int best_a = -1, best_b = -1, d1 = 360, d2 = 360;
@@ -380,6 +400,20 @@ LdpcDecoderHip::LdpcDecoderHip(const LdpcTableDesc* table, int out_bits_message,
             put(L.cnt + 1, false); // previous parity (rot 0 for i > 0)
         }
     }
+    // "Pure" packed builds have no plain node for layers > 0: a (layer, wave) record that is NOT in the packed format would do no work there and
+    // the decode would be silently wrong. The `fits` predicate above is a second copy of the record builder's rules: check the
+    // records that were actually BUILT, and refuse the table loudly instead of trusting the copy.
+    if (v2 && (!soft_bar_ || DVBS2_V2_PURE_SOFT) && v2_pure_class(dmax_)) {
+        for (int i = 1; i < sched_.q; i++)
+            for (int w = 0; w < 6; w++) {
+                const uint32_t h0 = wr[((size_t)i * 6 + w) * RSW];
+                const bool hazard = sched_.layers[i].block < 360;
+                if (!((h0 >> 13) & 1u) || (hazard && !((h0 >> 14) & 1u))) {
+                    err_ = "internal: a (layer, wave) record of a pure packed build is not in the packed format (layer " + std::to_string(i) + ", wave " + std::to_string(w) + ")";
+                    return;
+                }
+            }
+    }
     if (chain_plain_) { // the per-layer records of the plain build point chain layers to their per-wave records (bit 14)
         for (int i = 0; i < sched_.q; i++) if (chain_v2_layer[i]) hr[(size_t)i * RS] |= 1u << 14;
         HIP_OK(hipMemcpy(d_recs_, hr.data(), hr.size() * 4, hipMemcpyHostToDevice));
@@ -409,7 +443,7 @@ LdpcDecoderHip::LdpcDecoderHip(const LdpcTableDesc* table, int out_bits_message,
         const unsigned long long a = (unsigned long long)d_iters_, b = (unsigned long long)d_gsync_;
         int spin_max = kGroupSpinMax;
         if (const char* e = getenv("DVBS2_GROUP_SPIN_MAX")) spin_max = std::max(0, atoi(e)); // tests: 0 = a waiting member gives up at once (fallback path)
-        const uint32_t hd[kRecHeaderWords] = { (uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32), (uint32_t)G_, (uint32_t)spin_max, (uint32_t)(getenv("DVBS2_STAGGER") ? atoi(getenv("DVBS2_STAGGER")) : 0) /*experiments (DVBS2_EXP_STAGGER builds)*/, 0 };
+        const uint32_t hd[kRecHeaderWords] = { (uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32), (uint32_t)G_, (uint32_t)spin_max, 0, 0 };
         HIP_OK(hipMemcpy(d_recs_alloc_, hd, sizeof(hd), hipMemcpyHostToDevice));
     }
     if (const char* e = getenv("DVBS2_RESOLVE_ROUNDS")) resolve_rounds_ = std::max(0, std::min(8, atoi(e))); // tests: 0 forces the host-side leftover path
@@ -426,18 +460,11 @@ LdpcDecoderHip::LdpcDecoderHip(const LdpcTableDesc* table, int out_bits_message,
         // Keyed by the device this constructor actually runs on (hipGetDevice behind the guard), one entry per device ever seen; the
         // array is zeroed BEFORE its pointer is published. The counts survive the handles (a kernel gives its slot back when it ends);
         // they are not valid across hipDeviceReset().
-        static std::mutex mu;
-        static std::vector<std::pair<int, int*>> per_device;
-        std::lock_guard<std::mutex> lk(mu);
         int dv = -1;
         HIP_OK(hipGetDevice(&dv));
-        int* slots = nullptr;
-        for (const auto& e : per_device) if (e.first == dv) slots = e.second;
-        if (!slots) {
-            HIP_OK(hipMalloc(&slots, kCuSlots * 4));
-            if (hipMemset(slots, 0, kCuSlots * 4) != hipSuccess) { (void)hipFree(slots); err_ = "hipMemset of the per-CU counters failed"; return; }
-            per_device.push_back({ dv, slots });
-        }
+        std::string e;
+        int* slots = cu_slot_table(dv, &e);
+        if (!slots) { err_ = e; return; }
         d_cu_slots_ = slots;
     }
     kname_ = pr_ ? std::string(pr_w1_ ? "ldpc_layered_pr_kernel<w1>" : "ldpc_layered_pr_kernel") : "ldpc_layered_kernel<" + std::to_string(dmax_) + (dense_ ? ", dense>" : std::string(v2_ ? ", packed" : chain_plain_ ? ", chain" : "") + (solo_ ? ", solo>" : hz2_ ? ", hz2>" : soft_bar_ ? ", soft>" : ">"));

@@ -30,17 +30,14 @@
 // workgroup then sat through the L2's acknowledgement of its stores at every layer boundary. Waiting first costs nothing (the prefetch
 // is a layer old) and leaves the stores a whole layer to complete; no register is added. Measured (interleaved A/B): 1/4 normal +7 %,
 // B4 +3.6 %, 1/3 normal +8 %, 3/4 normal +3 % (23 tables, none loses); not in the software-barrier builds (S2X 154/180 -4 %).
-#ifndef DVBS2_PF_BIG
-#define DVBS2_PF_BIG 0 // measured (round 4, 17 tables of the classes 16-32): 3/4 normal +7 %, 8/9 +5 %, 9/10 +4 %, S2X 154/180 +9 %, the others +1...3 %, short 8/9 -0.7 %
-#endif
 #ifndef DVBS2_PF_SMALL_MAX_DMAX
 #define DVBS2_PF_SMALL_MAX_DMAX 8 // up to this degree class the whole record is double-buffered in scalar registers. Measured: class 8 loses 2-3 % without it
 #endif                            // (B4 119.7 -> 117.1 k), class 12 GAINS 1-3 % without it (3/5, 2/3 normal, S2X 11/20, T2 2/3, short 2/3; short 3/5 -0.7 %)
 #ifndef DVBS2_PREFETCH_AFTER_BARRIER_MAX_DMAX
 #define DVBS2_PREFETCH_AFTER_BARRIER_MAX_DMAX 8
 #endif
-#ifndef DVBS2_LDS_ONLY_BARRIER
-#define DVBS2_LDS_ONLY_BARRIER 0
+#ifndef DVBS2_PRETEST_CHUNK
+#define DVBS2_PRETEST_CHUNK 1 // the one-layer syndrome pre-test four edges per trip (round 6; 0: edge by edge)
 #endif
 #ifndef DVBS2_WAIT_RECORDS
 #define DVBS2_WAIT_RECORDS 1 // first measured on the plain class-8 build: B4 119.6 -> 115.9 k (off); re-measured once B4 ran the packed one-frame build: B4 133.2 -> 134.5 k, 2/5 normal +0.7 %, 3/5 +1 %, the others +-0.5 % (on)
@@ -54,9 +51,6 @@
 #ifndef DVBS2_TLC_FWALK_MIN_DMAX
 #define DVBS2_TLC_FWALK_MIN_DMAX 24 // the near pair of a two-level lane chain walked in float (six instructions per row, 16-byte operand records) in the
                                     // packed hazard nodes from this degree class up -- measured (round 5): 5/6 normal +3.1 %, 9/10 normal +0.35 %; 3/4 normal (class 16) -2.0 %
-#endif
-#ifndef DVBS2_TLC_SOFT
-#define DVBS2_TLC_SOFT 0 // experiments: the two-level lane chain also in the builds with software frame barriers
 #endif
 
 namespace dvbs2 {
@@ -123,11 +117,7 @@ __device__ __forceinline__ void frame_barrier(volatile lds_i32_t* ctr, int& epoc
 {
     // (Round 4, with no FLAT access left in the kernel: the barrier without the wait for outstanding vector memory operations that
     // __syncthreads() implies -- s_waitcnt lgkmcnt(0) + s_barrier -- measured again: +-0.3 % on every BASELINE table. Not used.)
-#if DVBS2_LDS_ONLY_BARRIER
-    if (!ctr) { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); return; } // (experiment: no wait for outstanding vector memory operations)
-#else
     if (!ctr) { __syncthreads(); return; } // hardware barrier of the workgroup (the default)
-#endif
     epoch += 6;
     asm volatile("" ::: "memory");
     if (lane == 0) __hip_atomic_fetch_add(const_cast<lds_i32_t*>(ctr), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -364,23 +354,6 @@ __device__ __forceinline__ void check_node(uint8_t* __restrict__ lds /*the whole
     }
 }
 
-// Low-register form of check_node for the high degree classes (LOWREG builds, DMAX >= kLowRegMinDmax). The plain node keeps
-// address, input and raw magnitude of every edge from its first phase to its last: 3 x 30 registers for degree 30 on top of
-// 24 message registers do not fit the 168 a wave has with three waves per SIMD, and the difference goes through scratch
-// (round 2: 52 spilled VGPRs, 1.5-1.6 x the algorithmic traffic). Here an edge keeps ONE register between the phases,
-//   pm = |Lb - mb| << 8 | (inp & 0xff)        (|Lb - mb| = raw magnitude + 1 in 0 .. 255, inp = sat8(L - m))
-// and its address is computed again in the output phase (four full-rate instructions). The two smallest are taken over
-// the pm words themselves (ordered by magnitude first); "mag == min0 ? min1 : min0" becomes "pm == smallest pm": if another
-// edge has the same magnitude then min1 == min0 and either choice gives the same value.
-constexpr int kLowRegMinDmax =
-#ifdef DVBS2_LOWREG_MIN_DMAX
-    DVBS2_LOWREG_MIN_DMAX; // experiments
-#else
-    1000; // OFF. Measured on MI355X in round 3 (interleaved A/B against the plain nodes, notes/r03_experiments.md): the form removes every
-          // spilled VGPR of the degree class 32 (52 -> 0) -- and S2X 154/180 LOSES 12 %, 9/10 normal 4-6 %, the classes 20 .. 28 5-12 %:
-          // the class is bound by VALU issue, not by its scratch traffic, and the form costs ~18 % more VALU work per edge
-#endif
-template <int DMAX, bool HZ2> constexpr bool kLowReg = DMAX >= kLowRegMinDmax;
 // two-level lane chain (check_node_hazard): the degree class 32 without the heavy-hazard paths (9/10 normal); not in the builds with software
 // frame barriers, which only tables without hazard layers run (S2X 154/180 lost 2.5 % to the larger kernel)
 // Which degree classes carry it is MEASURED (MI355X, interleaved A/B of whole tables, notes/r03_experiments.md): at run time the chain is
@@ -404,52 +377,6 @@ constexpr int kTlcLowRegMinDmax = 24; // from this degree class on a two-level-c
 __device__ __forceinline__ int pm_pack(int magp, int d) { return (int)__builtin_amdgcn_perm((uint32_t)magp, (uint32_t)d, 0x0c0c0400u); } // d.b0 | magp.b0 << 8
 __device__ __forceinline__ int pm_inp(int pm) { return __builtin_amdgcn_sbfe(pm, 0, 8); }
 __device__ __forceinline__ int pm_min_clamped(int p) { return clamp_mag((int)((uint32_t)p >> 8) - 1); } // R2 on a minimum: clamp(|x| - 1, 0, 126)
-template <int DEG, bool LAYER0>
-__device__ __forceinline__ void check_node_lr(const uint32_t* ent, int jj, int lb, const uint32_t* mw, uint32_t* nm)
-{
-    __builtin_amdgcn_s_setprio(0);
-    const int jjb = jj + lb, jjb360 = jjb - kM;
-    auto addr = [&](int k) -> int {
-        if (k >= DEG - 2 && !(LAYER0 && k == DEG - 1)) return jjb + (int)ent[2 * k];
-        return wrap_addr(jj, jjb, jjb360, ent[2 * k], ent[2 * k + 1]);
-    };
-    const bool last_valid = !LAYER0 || jj != 0;
-    int pm[DEG];
-    int signs = 0;
-#pragma unroll
-    for (int k = 0; k < DEG; k++) {
-        const int Lb = lds_rd(addr(k));
-        const int mb = (int)((mw[k >> 2] >> (8 * (k & 3))) & 0xffu);
-        int d = min(max(Lb - mb, -128), 127);
-        const int magp = (int)__builtin_amdgcn_sad_u16((uint32_t)Lb, (uint32_t)mb, 0u);
-        if (LAYER0 && k == DEG - 1) { d = last_valid ? d : 0; pm[k] = last_valid ? pm_pack(magp, d) : (kMagAbsent << 8); }
-        else pm[k] = pm_pack(magp, d);
-        signs ^= d;
-    }
-    __builtin_amdgcn_s_setprio(1);
-    int p0, p1;
-    two_smallest<DEG>(pm, p0, p1);
-    const int min0 = pm_min_clamped(p0), min1 = pm_min_clamped(p1);
-#pragma unroll
-    for (int w = 0; w < (DEG + 3) / 4; w++) nm[w] = 0;
-    int msgc[4];
-#pragma unroll
-    for (int k = 0; k < DEG; k++) {
-        const int other = pm[k] == p0 ? min1 : min0;
-        const int inp = pm_inp(pm[k]);
-        const int sg = (signs ^ inp) >> 31;
-        const int out = (other ^ sg) - sg;
-        const int nl = sat_sum_u8(inp, out);
-        if (!(LAYER0 && k == DEG - 1) || last_valid) lds_wr(addr(k), nl);
-        msgc[k & 3] = min(max(out, -32), 31);
-        if ((k & 3) == 3 || k == DEG - 1) {
-            if ((k & 3) < 3) { msgc[3] = 0; if ((k & 3) < 2) { msgc[2] = 0; if ((k & 3) < 1) msgc[1] = 0; } }
-            nm[k >> 2] = pack4_lo8(msgc[0], msgc[1], msgc[2], msgc[3]) ^ 0x80808080u;
-        }
-    }
-    __builtin_amdgcn_s_setprio(3);
-}
-
 // ---------------------------------------------------------------------------------------------------------------------------------
 // Packed check node ("v2", regular layers other than layer 0). The sweep is bound by VALU issue slots, so the node is
 // built to need fewer of them per edge:
@@ -808,7 +735,7 @@ constexpr int kMaxHazardHz2 = 12;
 constexpr int kMaxHazard12Dmax = 28; // (the degree class 32 has the two-level walk only: twelve ordered entries on top of 30 edges do not fit its registers)
 constexpr int kHazardWalk = 15; // header code: too many hazard entries, fall back to the single-wave chunk walk
 template <int DEG, int NC, bool LAYER0, bool PR = false, bool LAST = false, bool TWO = false /*two-level walk compiled in*/,
-          bool LR = false /*low-register form (see check_node_lr): regular entries keep one packed word, their addresses are computed twice*/,
+          bool LR = false /*low-register form: a regular entry keeps ONE word pm = |Lb - mb| << 8 | (inp & 0xff) between the phases and its address is computed twice (two-level-chain layers of the classes >= 24)*/,
           bool TLC = false /*two-level walk with the near pair as a LANE CHAIN (round 3), see below*/,
           bool CHAINOK = true /*false: no lane chain in this build (the 80-VGPR build since round 4, see kLaneChainBuilt)*/,
           bool CLASS8 = false /*the kernel of the degree class <= 8: early pair reads, walk on absolute addresses (DVBS2_EARLY_PAIR_MAXDEG)*/,
@@ -838,7 +765,7 @@ __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, con
     uint32_t sxp = 0;
     constexpr int NAD = LR ? NC : DEG; // LR: only the ordered entries keep their addresses
     int ad[NAD], inp[LR ? NC : DEG], mg[LR ? NC : DEG];
-    int pm[LR ? DEG : 1];  // LR: regular entry k keeps pm[k] (check_node_lr)
+    int pm[LR ? DEG : 1];  // LR: regular entry k keeps pm[k]
     // Lane-chain layers of the low degree classes: the pair's two LLR bytes are read WITH the regular entries (one LDS round trip for all
     // seven instead of three in a row on the wave that walks the chain afterwards). A value read here is used only by the rows for which
     // no earlier row of this layer writes that bit: entry 0 of the rows below 360 - block, entry 1 of the heads.
@@ -1479,8 +1406,7 @@ __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, con
 
 // degrees DMAX-7 .. DMAX are instantiated for kernel variant DMAX
 #define DVBS2_DEG_CASE(D) case D: if constexpr (D >= 3 && D <= DMAX && D > DMAX - 8) { \
-        if constexpr (kLowReg<DMAX, HZ2>) { if (layer0) check_node_lr<(D >= 3 ? D : 3), true>(ent, jj, lb, mw, nm); else check_node_lr<(D >= 3 ? D : 3), false>(ent, jj, lb, mw, nm); } \
-        else { if (layer0) check_node<(D >= 3 ? D : 3), true, false, false, TC>(lds_all, ent, jj, lb, mw, nm); else { if constexpr (!kPure) check_node<(D >= 3 ? D : 3), false, false, false, TC>(lds_all, ent, jj, lb, mw, nm); } } } break;
+        { if (layer0) check_node<(D >= 3 ? D : 3), true, false, false, TC>(lds_all, ent, jj, lb, mw, nm); else { if constexpr (!kPure) check_node<(D >= 3 ? D : 3), false, false, false, TC>(lds_all, ent, jj, lb, mw, nm); } } } break;
 #define DVBS2_DEG_SWITCH switch (deg) { \
         DVBS2_DEG_CASE(3) DVBS2_DEG_CASE(4) DVBS2_DEG_CASE(5) DVBS2_DEG_CASE(6) DVBS2_DEG_CASE(7) DVBS2_DEG_CASE(8) \
         DVBS2_DEG_CASE(9) DVBS2_DEG_CASE(10) DVBS2_DEG_CASE(11) DVBS2_DEG_CASE(12) DVBS2_DEG_CASE(13) DVBS2_DEG_CASE(14) \
@@ -1514,15 +1440,15 @@ __device__ __forceinline__ void check_node_hazard(uint8_t* __restrict__ lds, con
 #define DVBS2_HAZ_CALL1(D, NCV, LRV, TLCV) { \
         if (layer0) check_node_hazard<D, NCV, true, false, false, HZ2, LRV, TLCV, (MINW == 1), (DMAX <= 8), false, 0, false, TC>(lds_all, ent, jj, lb, work, block, block2, mw, nm, 0, nullptr, htab, hb_ctr, hb_epoch, hb_lane, hz_ph); else { if constexpr (!kPure) check_node_hazard<D, NCV, false, false, false, HZ2, LRV, TLCV, (MINW == 1), (DMAX <= 8), false, 0, false, TC>(lds_all, ent, jj, lb, work, block, block2, mw, nm, 0, nullptr, htab, hb_ctr, hb_epoch, hb_lane, hz_ph); } }
 #define DVBS2_HAZ_CALL(D, NCV) { if constexpr (D - 2 >= NCV) { \
-        if constexpr (kTlc<DMAX, HZ2> && (!SOFT || DVBS2_TLC_SOFT) && MINW == 1 && (NCV == 4 || NCV == 8)) { if (block2 > 0 && htab != nullptr) DVBS2_HAZ_CALL1(D, NCV, (DMAX >= kTlcLowRegMinDmax), true) else DVBS2_HAZ_CALL1(D, NCV, (kLowReg<DMAX, HZ2>), false) } \
-        else DVBS2_HAZ_CALL1(D, NCV, (kLowReg<DMAX, HZ2>), false) } }
+        if constexpr (kTlc<DMAX, HZ2> && !SOFT && MINW == 1 && (NCV == 4 || NCV == 8)) { if (block2 > 0 && htab != nullptr) DVBS2_HAZ_CALL1(D, NCV, (DMAX >= kTlcLowRegMinDmax), true) else DVBS2_HAZ_CALL1(D, NCV, false, false) } \
+        else DVBS2_HAZ_CALL1(D, NCV, false, false) } }
 #define DVBS2_HAZ_CASE(D) case D: if constexpr (D >= 4 && D <= DMAX && D > DMAX - 8) { \
         if (nc == 2) DVBS2_HAZ_CALL((D >= 4 ? D : 4), 2) else if (nc == 4) DVBS2_HAZ_CALL((D >= 4 ? D : 4), 4) else { if constexpr (HZ2 && DMAX <= kMaxHazard12Dmax) { if (nc == 8) DVBS2_HAZ_CALL((D >= 4 ? D : 4), 8) else DVBS2_HAZ_CALL((D >= 4 ? D : 4), 12) } else DVBS2_HAZ_CALL((D >= 4 ? D : 4), 8) } } break;
 // The same with the packed first / last phase (check_node_hazard<..., V2P>): regular layers i > 0 of the builds with packed nodes whose
 // wave record the host laid out in the packed format (header bit 14); the ordered phase is the plain one, instantiation for instantiation.
 #define DVBS2_HAZP_CALL1(D, NCV, TLCV) { check_node_hazard<D, NCV, false, false, false, HZ2, false, TLCV, (MINW == 1), (DMAX <= 8), true, DMAX, P6, TC>(lds_all, ent, jj, lb, work, block, block2, mw, nm, 0, nullptr, htab, hb_ctr, hb_epoch, hb_lane, hz_ph); }
 #define DVBS2_HAZP_CALL(D, NCV) { if constexpr (D - 2 >= NCV) { \
-        if constexpr (kTlc<DMAX, HZ2> && (!SOFT || DVBS2_TLC_SOFT) && MINW == 1 && (NCV == 4 || NCV == 8)) { if (block2 > 0 && htab != nullptr) DVBS2_HAZP_CALL1(D, NCV, true) else DVBS2_HAZP_CALL1(D, NCV, false) } \
+        if constexpr (kTlc<DMAX, HZ2> && !SOFT && MINW == 1 && (NCV == 4 || NCV == 8)) { if (block2 > 0 && htab != nullptr) DVBS2_HAZP_CALL1(D, NCV, true) else DVBS2_HAZP_CALL1(D, NCV, false) } \
         else DVBS2_HAZP_CALL1(D, NCV, false) } }
 #define DVBS2_HAZP_CASE(D) case D: if constexpr (D >= 4 && D <= DMAX && D > DMAX - 8) { \
         if (nc == 2) DVBS2_HAZP_CALL((D >= 4 ? D : 4), 2) else if (nc == 4) DVBS2_HAZP_CALL((D >= 4 ? D : 4), 4) else DVBS2_HAZP_CALL((D >= 4 ? D : 4), 8) } break;
@@ -1739,13 +1665,6 @@ __global__ __launch_bounds__(SOLO ? kSoloThreads : kThreads, SOLO ? 4 : MINW) vo
     int hb_epoch = 0;
     const int hb_lane = lane;
     __syncthreads();
-#ifdef DVBS2_EXP_STAGGER
-    // experiment: with software frame barriers nothing couples the two frames of a workgroup; the second one starts late (header
-    // word 6: units of ~4 k cycles), so that its ordered hazard steps fall into the first one's regular layers
-    if constexpr (SOFT) {
-        if (half == 1) { const uint32_t dl = (recs - kRecHeaderWords)[6]; for (uint32_t c = 0; c < dl; c++) __builtin_amdgcn_s_sleep(64); }
-    }
-#endif
     TSTAMP(tB); tm_load = tB - tA;
 
     // Messages go through a buffer descriptor based at this frame's records: the per-lane offset (row * 4, plus the
@@ -1777,9 +1696,6 @@ __global__ __launch_bounds__(SOLO ? kSoloThreads : kThreads, SOLO ? 4 : MINW) vo
                 else if (nf >= 1) dst[w] = (uint32_t)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(mrs, r4 >> 1, soff + w * (kMsgStride * 4), 1 /* sc0: a sub-dword store does not update a line held in the vector L1 */);
                 else dst[w] = 0u;
             }
-#ifdef DVBS2_EXP_ONEWORD // timing-only bound (wrong results): half of a check's message words move, the rest is derived
-            else if (w >= (MW + 1) / 2) dst[w] = 0u; // (derived from the loaded half where the words are consumed: DVBS2_ONEWORD_FILL)
-#endif
             else dst[w] = MSG_LD(soff, w, r4);
         }
     };
@@ -1791,17 +1707,9 @@ __global__ __launch_bounds__(SOLO ? kSoloThreads : kThreads, SOLO ? 4 : MINW) vo
                 if (nf >= DVBS2_P6_DW) MSG_ST(src[w], soff, w, r4);
                 else if (nf >= 1) __builtin_amdgcn_raw_buffer_store_b16((unsigned short)src[w], mrs, r4 >> 1, soff + w * (kMsgStride * 4), 0);
             }
-#ifdef DVBS2_EXP_ONEWORD
-            else if (w >= (MW + 1) / 2) { asm volatile("" :: "v"(src[w])); }
-#endif
             else MSG_ST(src[w], soff, w, r4);
         }
     };
-#ifdef DVBS2_EXP_ONEWORD // (the words that were not loaded: a function of the loaded ones, computed where a layer consumes its messages)
-#define DVBS2_ONEWORD_FILL(p, w) ((w) >= (MW + 1) / 2 ? ((p)[(w) - (MW + 1) / 2] ^ 0x01030107u) : (p)[w])
-#else
-#define DVBS2_ONEWORD_FILL(p, w) ((p)[w])
-#endif
     // bnl = 0 before the first update (layered_decoder.hh:27-31,149): a frame's first sweep (it == 0, in the first pass or
     // when a frame that stopped at once is resumed) takes offset-binary zero bytes instead of loading them -- no memset
     // of the record area, no read traffic in sweep 0
@@ -1822,6 +1730,32 @@ __global__ __launch_bounds__(SOLO ? kSoloThreads : kThreads, SOLO ? 4 : MINW) vo
             const uint32_t* rec = recs + (size_t)i0 * RS;
             const int deg = (int)(rec[0] & 0xffu) + 2;
             uint32_t x = 0, z = 0;
+            // per build, measured (round 6, interleaved A/B of whole tables against the edge-by-edge loop): 9/10 normal +4.7 %, 5/6 +4.0 %, 8/9 +2.0 %,
+            // 4/5 +1.3 %, S2X 25/36 +1.6 %, 1/4 normal +1.0 %, short 3/5 (the 80-VGPR build) +45 %; 3/4 normal -2.5 % and short 2/3 -1.0 % (class 16),
+            // S2X 154/180 -1.8 % (class 32 with software barriers), B4 and short 1/4 unchanged
+            constexpr bool kPretestChunk = (DVBS2_PRETEST_CHUNK != 0) && DMAX != 16 && !(DMAX == 32 && SOFT);
+            if constexpr (kPretestChunk) {
+            // Round 6: FOUR edges per trip -- their eight record words in one scalar load, the four LDS reads in flight together. Edge by
+            // edge the loop paid one scalar-cache round trip and one LDS round trip per edge (~300 cycles x 30 edges of a 9/10 normal
+            // check: the syndrome phase was 19 k of its 342 k cycles per update, cycle stamps). (records are padded to DMAX entries,
+            // DMAX is a multiple of four: the last trip never reads past its record; an edge past the degree reads byte `tid` and is ignored)
+            for (int k0 = 0; k0 < deg; k0 += 4) {
+                uint32_t e[8], v[4];
+#pragma unroll
+                for (int u = 0; u < 8; u++) e[u] = rec[4 + 2 * k0 + u];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int a0 = tid + (int)e[2 * u] - ((uint32_t)tid < e[2 * u + 1] ? 0 : kM);
+                    v[u] = (uint32_t)lds[k0 + u < deg ? a0 : tid];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    uint32_t w = v[u] ^ (TC ? 0x80u : 0x00u); // offset-binary value
+                    if (i0 == 0 && k0 + u == deg - 1 && tid == 0) w = 0x81u; // check (0,0) has no previous parity: neutral +1
+                    if (k0 + u < deg) { x ^= w; z |= (w == 0x80u); }
+                }
+            }
+            } else
             for (int k = 0; k < deg; k++) {
                 const int a0 = tid + (int)rec[4 + 2 * k] - ((uint32_t)tid < rec[5 + 2 * k] ? 0 : kM);
                 uint32_t v = (uint32_t)lds[a0] ^ (TC ? 0x80u : 0x00u); // offset-binary value
@@ -1929,9 +1863,6 @@ __global__ __launch_bounds__(SOLO ? kSoloThreads : kThreads, SOLO ? 4 : MINW) vo
         if (work) {
 #pragma unroll
             for (int w = 0; w < MW; w++) {
-#ifdef DVBS2_EXP_ONEWORD
-                if (w >= (MW + 1) / 2) { pre[w] = 0u; continue; }
-#endif
                 pre[w] = zero_msgs ? 0x80808080u : MSG_LD(0, w, row4);
             }
         }
@@ -1939,11 +1870,10 @@ __global__ __launch_bounds__(SOLO ? kSoloThreads : kThreads, SOLO ? 4 : MINW) vo
         // (an un-prefetched s_load at the head of every layer was a quarter of the sweep time). Small records are
         // buffered whole; for the large ones only every 8th dword is carried over -- enough to pull each cache
         // line of the next record into the scalar cache -- and the rest is loaded at the top of the layer.
-        // DVBS2_PF_BIG: carried-over words of the large records. 8 (rounds 1-3): every 8th word. 0 (experiment, round 4): none -- the header
-        // words only; the ISA of the class 32 shows each carried word as its own `s_load_dword; s_waitcnt lgkmcnt(0); v_writelane` (no scalar
-        // register is free to hold it), eight exposed scalar round trips at every layer head, and the records of a table (5-7 KB) stay in
-        // the scalar cache anyway.
-        constexpr int PF = DMAX <= DVBS2_PF_SMALL_MAX_DMAX ? 1 : (DVBS2_PF_BIG != 0 ? DVBS2_PF_BIG : 2 * DMAX);
+        // (Rounds 1-3 carried every 8th word of the large records over from the previous layer; round 4 measured none -- the header words only --
+        // 1-9 % faster on 16 of 17 tables of the classes 16-32: each carried word was its own `s_load_dword; s_waitcnt lgkmcnt(0); v_writelane`
+        // at every layer head, and the records of a table (5-7 KB) stay in the scalar cache anyway.)
+        constexpr int PF = DMAX <= DVBS2_PF_SMALL_MAX_DMAX ? 1 : 2 * DMAX;
         // the sweep reads the records of its own WAVE (check_node_v2): wrecs[(layer * 6 + wave) * RS]
         const uint32_t* wr = V2 ? wrecs + (size_t)wave_u * rec_stride_wave(DMAX) : recs; // builds without packed nodes read the per-layer records
         uint32_t nhdr = wr[0], ninfo = wr[1]; // word 1: message format of the NEXT layer for this wave (degree | packed << 8)
@@ -1984,7 +1914,7 @@ __global__ __launch_bounds__(SOLO ? kSoloThreads : kThreads, SOLO ? 4 : MINW) vo
             lds_u32_t* htab = ((hdr >> 12) & 1u) ? sv : nullptr; // lane-chain scratch: the sign-vector area is idle during a sweep
             const int block = (int)(hdr >> 16);
             int block2 = 0; // hazard layers: rows per outer block of the two-level walk (0: off)
-            if constexpr (HZ2 || (kTlc<DMAX, HZ2> && (!SOFT || DVBS2_TLC_SOFT) && MINW == 1)) { if (block < kM) block2 = (int)wr[(size_t)i * RSW + 2]; }
+            if constexpr (HZ2 || (kTlc<DMAX, HZ2> && !SOFT && MINW == 1)) { if (block < kM) block2 = (int)wr[(size_t)i * RSW + 2]; }
             const bool layer0 = (i == 0);
             const int mso = i * kLayerBytes; // scalar byte offset of this layer's message records
             TSTAMP(tA);
@@ -1999,7 +1929,7 @@ __global__ __launch_bounds__(SOLO ? kSoloThreads : kThreads, SOLO ? 4 : MINW) vo
                     // v2: this wave's record is in the packed node's format (two's complement messages)
                     uint32_t mw[MW], nm[MW];
 #pragma unroll
-                    for (int w = 0; w < MW; w++) mw[w] = zero_msgs ? (v2 ? 0u : 0x80808080u) : DVBS2_ONEWORD_FILL(pre, w);
+                    for (int w = 0; w < MW; w++) mw[w] = zero_msgs ? (v2 ? 0u : 0x80808080u) : pre[w];
                     if (i + 1 < q && !zero_msgs) msg_load(pre, mso + kLayerBytes, row4, npacked, ndeg);
                     if constexpr (V2) { if (v2) { DVBS2_V2_SWITCH } else DVBS2_DEG_SWITCH } else DVBS2_DEG_SWITCH
                     DVBS2_WAIT_VM0();
@@ -2008,11 +1938,7 @@ __global__ __launch_bounds__(SOLO ? kSoloThreads : kThreads, SOLO ? 4 : MINW) vo
                 TSTAMP(tC); tm_body += tC - tB;
                 if (TIMING && tdbg && f == 0 && tid == 0) tdbg[(size_t)n_frames * 48 + i] += tC - tA; // per-layer cycles of frame 0, wave 0 (incl. its barrier)
             } else {
-#ifdef DVBS2_EXP_NOHAZ // register-pressure experiments: the regular path alone
-                if (false) {
-#else
                 if (nc != kHazardWalk) {
-#endif
                     // sequential-order hazard inside the layer: check_node_hazard (every thread takes every barrier)
                     const int jj = row;
                     // hv2: packed single-pair chain (check_node_chain_v2): two's complement messages. In a build without the packed regular
@@ -2027,7 +1953,7 @@ __global__ __launch_bounds__(SOLO ? kSoloThreads : kThreads, SOLO ? 4 : MINW) vo
                     }
                     uint32_t mw[MW], nm[MW];
 #pragma unroll
-                    for (int w = 0; w < MW; w++) mw[w] = (work && !zero_msgs) ? DVBS2_ONEWORD_FILL(pre, w) : (hv2 ? 0u : 0x80808080u);
+                    for (int w = 0; w < MW; w++) mw[w] = (work && !zero_msgs) ? pre[w] : (hv2 ? 0u : 0x80808080u);
                     if (work && i + 1 < q && !zero_msgs) msg_load(pre, mso + kLayerBytes, row4, npacked, ndeg);
                     // hvp: the generic hazard node with the packed first / last phase (header bit 14 of this wave's record; every wave of the
                     // layer runs the same ordered phase, whichever form its own record has)

@@ -64,6 +64,7 @@ SYMBOLS = {
     "dvbs2_ldpc_fallback_rounds": (_i, [_vp]),
     "dvbs2_measure_host_copy": (_i, [_i, C.c_size_t, _i, _i, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "dvbs2_measure_shader_clock": (_i, [_i, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "dvbs2_debug_cu_slot_table": (_i, [_i, _i, C.POINTER(C.c_ulonglong), _ip]),
     "dvbs2_bch_create": (_i, [C.POINTER(_vp), _i, _i, _i, _i, _i]),
     "dvbs2_bch_create_raw": (_i, [C.POINTER(_vp), _i, C.c_uint32, _i, _i, _i, _i]),
     "dvbs2_bch_destroy": (None, [_vp]),

@@ -21,7 +21,10 @@ def init_from_env(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    # DVBS2_FORCE_PG=1: initialise the process group at WORLD_SIZE = 1 as well (tests: the RCCL rendezvous and device all-reduce of the
+    # N > 1 launch, exercised on a one-GPU box; needs MASTER_ADDR / MASTER_PORT like any launch)
+    force = os.environ.get("DVBS2_FORCE_PG", "") not in ("", "0")
+    if (world > 1 or force) and not dist.is_initialized():
         if backend is None:
             backend = os.environ.get("DVBS2_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         kw = {}
@@ -31,6 +34,8 @@ def init_from_env(backend=None):
             # chose DVBS2_DIST_BACKEND=gloo for that experiment
             ndev = max(1, torch.cuda.device_count())
             kw["device_id"] = torch.device("cuda", local % ndev)
+        if world == 1:
+            kw.update(rank=0, world_size=1)
         dist.init_process_group(backend=backend, **kw)
     if torch.cuda.is_available():
         local = local % max(1, torch.cuda.device_count())

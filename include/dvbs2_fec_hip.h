@@ -146,6 +146,12 @@ int dvbs2_measure_host_copy(int device, size_t bytes, int n_streams, int kind, d
  * cycle stamps and the SQ cycle counters count in) over the s_memrealtime delta (100 MHz) of one workgroup. bench.py converts the SQ pass's
  * cycle counts with it instead of assuming the nominal 2.4 GHz (roofline.limiter). kernel_ms (nullable): duration of the probe. */
 int dvbs2_measure_shader_clock(int device, double* ghz, double* kernel_ms);
+/* Diagnostics / tests. The one-frame sweep kernels keep one array of per-CU wave-pattern counters PER DEVICE, shared by all handles of that
+ * device (two workgroups on a CU take complementary patterns whichever handle launched them). Returns the array kept for `device_key`
+ * (created on `device` when the key is new) and how many of its words are non-zero (all zero while no sweep kernel runs): the same key gives
+ * the same array, another key another one -- exercised with keys a one-GPU box does not have (the multi-GPU split of SURVEY 8(e) runs one
+ * process per GPU, but several handles on several devices of ONE process are allowed: INTEGRATION.md). */
+int dvbs2_debug_cu_slot_table(int device, int device_key, unsigned long long* table_address, int* nonzero_words);
 /* which sweep kernel the handle launches, as rocprofv3 names it: "ldpc_layered_kernel<DMAX>" or
  * "ldpc_layered_pr_kernel" (parity LLRs kept in registers / message records; chosen per table, identical results) */
 const char* dvbs2_ldpc_kernel_name(const dvbs2_ldpc_t* h);

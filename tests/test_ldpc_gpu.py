@@ -485,6 +485,29 @@ def test_full_batch_of_the_benchmark_input_vs_reference(table, nf, trials, seed)
     dec.close()
 
 
+def test_cu_slot_table_is_per_device():
+    """The per-device table of the one-frame kernels' wave-pattern counters (csrc/ldpc_hip.hip, cu_slot_table), exercised with device KEYS
+    a one-GPU box does not have: one array per key, the same array for the same key, zeroed, and the array of the real device is the one
+    the handles use (its counters are back to zero once a decode has finished)."""
+    import ctypes as C
+    addr, nz = C.c_ulonglong(), C.c_int()
+    seen = {}
+    for key in (0, 1, 7, 1, 0, 7):
+        capi.check(capi.lib.dvbs2_debug_cu_slot_table(0, key, C.byref(addr), C.byref(nz)))
+        assert nz.value == 0 and addr.value != 0
+        assert seen.setdefault(key, addr.value) == addr.value
+    assert len(set(seen.values())) == 3
+    table = "S2_TABLE_B4"  # one-frame packed build
+    N, K, _, _ = T.ldpc_info(table)
+    dec = LdpcDecoder(table=table, message_bits=K, group_size=32, max_frames=64, max_trials=5, outputmode=capi.OM_MESSAGE)
+    assert "solo" in dec.kernel_name
+    dec.work(T.llr_noise(64, N, 3))
+    capi.check(capi.lib.dvbs2_debug_cu_slot_table(0, 0, C.byref(addr), C.byref(nz)))
+    assert addr.value == seen[0] and nz.value == 0  # every workgroup gave its pattern slot back
+    dec.close()
+    assert capi.lib.dvbs2_debug_cu_slot_table(0, 0, None, None) == capi.EINVAL
+
+
 def test_two_devices_from_one_process():
     """one host thread + stream per GPU. Two handles on devices 0 and 1 driven from ONE process (the caller's
     current device stays where it was, csrc/device_guard.h), each decoding its contiguous G-aligned share; together they equal

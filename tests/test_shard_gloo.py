@@ -122,3 +122,34 @@ def test_bench_n2_branch_runs_on_one_gpu():
     for mode in ("pageable", "registered"):
         assert len(host[mode]["per_rank_frames_per_s"]) == 2 and all(v > 0 for v in host[mode]["per_rank_frames_per_s"])
     assert d["fallback_rounds"] == 0
+
+
+@pytest.mark.gpu
+def test_rccl_process_group_at_world_size_one():
+    """The RCCL side of the N > 1 launch on the one GPU of the test box: DVBS2_FORCE_PG=1 makes shard.init_from_env
+    initialise the `nccl` (= RCCL) process group with device_id at WORLD_SIZE = 1; barrier_sync, max / sum / gather over ranks then run
+    their all-reduces on DEVICE tensors through RCCL. In a process of its own (a process group is per process)."""
+    code = r"""
+import os, sys
+sys.path.insert(0, os.path.join(%r, "gr-dvbs2rx_amd", "python"))
+import torch, torch.distributed as dist
+from dvbs2rx_amd import shard
+world, rank, local = shard.init_from_env()
+assert (world, rank, local) == (1, 0, 0) and dist.is_initialized() and dist.get_backend() == "nccl"
+dev = torch.device("cuda", local)
+torch.cuda.set_device(local)
+shard.barrier_sync()
+assert shard.max_over_ranks(3.25, device=dev) == 3.25
+assert shard.sum_over_ranks(2.5, device=dev) == 2.5
+assert shard.gather_over_ranks(7.0, device=dev) == [7.0]
+t = torch.arange(1024, dtype=torch.float32, device=dev)
+dist.all_reduce(t)
+assert float(t.sum().item()) == float(sum(range(1024)))
+shard.finalize()
+print("rccl ok")
+""" % ROOT
+    env = dict(os.environ, DVBS2_FORCE_PG="1", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29617",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("DVBS2_DIST_BACKEND", None)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "rccl ok" in r.stdout, r.stdout + r.stderr
