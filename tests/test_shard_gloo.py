@@ -2,6 +2,8 @@
 with the CPU oracle standing in for the GPU decoder so that 'sharded decode == unsharded decode' is checked too."""
 import os
 import socket
+import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -147,7 +149,7 @@ dist.all_reduce(t)
 assert float(t.sum().item()) == float(sum(range(1024)))
 shard.finalize()
 print("rccl ok")
-""" % ROOT
+""" % T.ROOT
     env = dict(os.environ, DVBS2_FORCE_PG="1", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29617",
                HSA_ENABLE_IPC_MODE_LEGACY="0")
     env.pop("DVBS2_DIST_BACKEND", None)
