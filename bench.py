@@ -600,6 +600,8 @@ def chain_host_entry(np, torch, capi, FecChain, dev, local, nf, trials, G, strea
         for h in hs:
             h.close()
         del hx, dx, dm, dc, hm, hc
+    pipe["what"] = ("two handles x the caller's own page-locked buffers, WHOLE-call copies: H2D + dvbs2_chain_enqueue_device + D2H per call, call i finished right before call i + 2 "
+                    "is issued; the two calls' input copies share the host link, so this form is NOT faster than the synchronous entry, which overlaps copies and kernels chunk by chunk itself")
     res["pipelined"] = pipe
     return res
 
