@@ -130,7 +130,9 @@ LdpcDecoderHip::LdpcDecoderHip(const LdpcTableDesc* table, int out_bits_message,
     // medium table gains 12-43 % from the second workgroup per CU. On normal frames the classic kernel is as fast or
     // faster since its hazard layers run as lane chains (B4: 109 k vs 106 k frames/s; thin-layer tables lose up to
     // 20 % with parity-in-records). DVBS2_PR=0 / 1 overrides.
-    pr_ = degmax <= 7 && sched_.N < 64800;
+    // Round 6: also the two NORMAL tables of check degree <= 4 (1/4 normal, S2X 2/9 normal: one-dword records, four frames per CU): interleaved A/B
+    // 154.1 -> 158.9 k and 152.8 -> 157.6 k frames/s (+3.1 %); the other normal tables of degree <= 7 lose with it (2/5 0.958, B4 0.989, 1/3 0.941, S2X 13/45 0.849).
+    pr_ = degmax <= 7 && (sched_.N < 64800 || degmax <= 4);
     if (const char* e = getenv("DVBS2_PR")) pr_ = degmax <= 7 && atoi(e) != 0;
     for (const LdpcLayer& L : sched_.layers)
         if (L.block < 360 && (L.n_conflict > 4 || (L.n_conflict > 2 ? 4 : 2) > L.cnt)) pr_ = false;

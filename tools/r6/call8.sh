@@ -18,5 +18,5 @@ d=json.loads([l for l in open(sys.argv[1]+'/bench_host.json') if l.startswith('{
 h=d['configs']['config3_host']
 for k in ('worst_case','operating_point'):
     for n,v in h[k]['calls'].items(): print(k,n, round(v['frames_per_s']), round(v['frac_of_resident'],3), round(v['frac_of_link_bound'],3))
-    for n,v in h[k]['pipelined'].items(): print(k,'pipe',n, round(v['frames_per_s']), round(v['frac_of_resident'],3), round(v['frac_of_link_bound'],3))
+    for n,v in ((a,b) for a,b in h[k]['pipelined'].items() if isinstance(b,dict)): print(k,'pipe',n, round(v['frames_per_s']), round(v['frac_of_resident'],3), round(v['frac_of_link_bound'],3))
 PY
