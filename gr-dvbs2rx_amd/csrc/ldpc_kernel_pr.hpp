@@ -24,6 +24,15 @@
 #ifndef DVBS2_PR_DEFER_STORE
 #define DVBS2_PR_DEFER_STORE 1
 #endif
+// Round 6: the degree-3 / 4 node of the one-dword-record kernel takes the minimum over the OTHER links directly (see check_node_pr6). Interleaved A/B against
+// "two smallest + select" (three repetitions, gpurun_out/r6m): short 1/4 1059.8 -> 1074.1 k (+1.3 %), S2X short 1220 -> 1232 k, medium 1/5 and 11/45 +1.0 / +1.1 %,
+// 1/4 normal and S2X 2/9 normal +0.9 / +1.2 %; the kernel's other tables (two-dword records) 1.000 / 1.001.
+#ifndef DVBS2_PR6_DIRECT
+#define DVBS2_PR6_DIRECT 1
+#endif
+#ifndef DVBS2_PR_PRETEST_AHEAD
+#define DVBS2_PR_PRETEST_AHEAD 0
+#endif
 
 namespace dvbs2 {
 
@@ -62,6 +71,8 @@ __device__ __forceinline__ uint32_t pr_w1_compress(const uint32_t* nm)
 
 // check_node<DEG, LAYER0, PR = true, LAST> (ldpc_kernel.hpp) on the one-dword record itself: messages come out of and go back into
 // the 6-bit fields without the detour through byte words (two instructions per message each way instead of ~4.5).
+__device__ __forceinline__ uint32_t vmin3_u32(uint32_t a, uint32_t b, uint32_t c) { uint32_t r; asm("v_min3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(c)); return r; }
+__device__ __forceinline__ uint32_t usub_sat1(uint32_t a) { uint32_t r; asm("v_sub_u32_e64 %0, %1, 1 clamp" : "=v"(r) : "v"(a)); return r; } // max(a - 1, 0)
 template <int DEG, bool LAYER0, bool LAST>
 __device__ __forceinline__ uint32_t check_node_pr6(uint8_t* __restrict__ lds, const uint32_t* ent, int jj, int lb, uint32_t x /*this layer's record*/,
                                                    int own_in, int* carry)
@@ -90,20 +101,47 @@ __device__ __forceinline__ uint32_t check_node_pr6(uint8_t* __restrict__ lds, co
     for (int k = 0; k < DEG; k++) {
         const int mb = (int)((x >> (6 * k)) & 0x3fu) + 96; // field = m + 32 -> offset-binary byte m + 128
         int d = min(max(Lb[k] - mb, -128), 127);
+#if DVBS2_PR6_DIRECT
+        int mag = (int)__builtin_amdgcn_sad_u16((uint32_t)Lb[k], (uint32_t)mb, 0u); // |Lb - mb| in [0, 255]
+#else
         int mag = mag_raw(Lb[k], mb);
+#endif
         if (LAYER0 && k == DEG - 1) { d = last_valid ? d : 0; mag = last_valid ? mag : kMagAbsent; }
         inp[k] = d; mg[k] = mag;
         signs ^= d;
     }
     __builtin_amdgcn_s_setprio(1);
+#if DVBS2_PR6_DIRECT
+    // Degree 3 / 4: the minimum over the OTHER links directly (R3 + R5's selection in one): v_min3_u32 of the other raw |Lb - mb| and 127
+    // (R2's qabs bound), then one saturating subtract of the offset -- 3 half-rate + 3 full-rate instructions at degree 3 and 6 + 4 at degree 4,
+    // against 7 + 4 and 10 + 5 for "two smallest, clamp both, select per link".
+    int oth[DEG];
+    if constexpr (DEG == 3) {
+        oth[0] = (int)vmin3_u32((uint32_t)mg[1], (uint32_t)mg[2], 127u);
+        oth[1] = (int)vmin3_u32((uint32_t)mg[0], (uint32_t)mg[2], 127u);
+        oth[2] = (int)vmin3_u32((uint32_t)mg[0], (uint32_t)mg[1], 127u);
+    } else {
+        const uint32_t m01 = min((uint32_t)mg[0], (uint32_t)mg[1]), m23 = min((uint32_t)mg[2], (uint32_t)mg[3]);
+        oth[0] = (int)vmin3_u32((uint32_t)mg[1], m23, 127u);
+        oth[1] = (int)vmin3_u32((uint32_t)mg[0], m23, 127u);
+        oth[2] = (int)vmin3_u32((uint32_t)mg[3], m01, 127u);
+        oth[3] = (int)vmin3_u32((uint32_t)mg[2], m01, 127u);
+    }
+    (void)min0; (void)min1;
+#else
     two_smallest<DEG>(mg, min0, min1);
     min0 = clamp_mag(min0); min1 = clamp_mag(min1);
     const int s01 = min0 + min1;
+#endif
     uint32_t y = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         if (k < DEG) {
+#if DVBS2_PR6_DIRECT
+            const int other = (int)usub_sat1((uint32_t)oth[k]);
+#else
             const int other = s01 - vmed3_i32(mg[k], min0, min1);
+#endif
             const int sg = (signs ^ inp[k]) >> 31;
             const int out = (other ^ sg) - sg;
             const int nl = sat_sum_u8(inp[k], out);
@@ -249,6 +287,28 @@ __global__ __launch_bounds__(kThreads, 6) void ldpc_layered_pr_kernel(
             const uint32_t* rec = recs + (size_t)i0 * RS;
             const int deg = (int)(rec[0] & 0xffu) + 2;
             uint32_t x = 0, z = 0;
+            if constexpr (DVBS2_PR_PRETEST_AHEAD == 2 || (DVBS2_PR_PRETEST_AHEAD == 1 && W1)) {
+            // Round 6: the two parity bytes that live in the message records (HBM / L2) are requested FIRST and together; edge by edge each was one
+            // round trip to memory in front of the next edge's LDS read.
+            const bool own_rec = i0 != q - 1, prev_rec = i0 != 0; // uniform
+            uint32_t wo = 0, wp = 0;
+            if (own_rec) wo = msg_base[((i0 + 1) * RW + PW) * kMsgStride + tid];  // own parity P[i0]
+            if (prev_rec) wp = msg_base[(i0 * RW + PW) * kMsgStride + tid];       // previous parity P[i0-1]
+            auto lds_entry = [&](int k) -> uint32_t {
+                const int a0 = tid + (int)rec[4 + 2 * k] - ((uint32_t)tid < rec[5 + 2 * k] ? 0 : kM);
+                return lds[a0];
+            };
+            for (int k = 0; k < deg - 2; k++) { const uint32_t v = lds_entry(k); x ^= v; z |= (v == 0x80u); }
+            {
+                const uint32_t v = own_rec ? wo >> 24 : lds_entry(deg - 2);
+                x ^= v; z |= (v == 0x80u);
+            }
+            {
+                uint32_t v = prev_rec ? wp >> 24 : lds_entry(deg - 1);
+                if (i0 == 0 && tid == 0) v = 0x81u; // check (0,0) has no previous parity
+                x ^= v; z |= (v == 0x80u);
+            }
+            } else
             for (int k = 0; k < deg; k++) {
                 uint32_t v;
                 if (k == deg - 2 && i0 != q - 1) v = msg_base[((i0 + 1) * RW + PW) * kMsgStride + tid] >> 24;       // own parity P[i0]

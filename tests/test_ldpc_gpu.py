@@ -263,7 +263,10 @@ def test_kernel_variant_policy(monkeypatch):
     assert name("S2_TABLE_C5") == "ldpc_layered_kernel<12, dense>"  # short 3/5: 16 of 18 layers are hazard layers
     assert name("S2_TABLE_C5", DVBS2_DENSE="0", DVBS2_V2="0", DVBS2_SOLO="0") == "ldpc_layered_kernel<12>"
     assert name("S2_TABLE_C1", DVBS2_PR="0", DVBS2_V2="0", DVBS2_SOLO="0") == "ldpc_layered_kernel<4>"  # degree <= 4: one message dword per check
-    assert name("S2_TABLE_B1") == expect("S2_TABLE_B1", 4)
+    assert name("S2_TABLE_B1") == "ldpc_layered_pr_kernel<w1>"       # 1/4 normal: the NORMAL tables of degree <= 4 take the one-dword-record kernel too (round 6, by rule)
+    assert name("S2X_TABLE_B1") == "ldpc_layered_pr_kernel<w1>"      # S2X 2/9 normal likewise
+    assert name("S2_TABLE_B1", DVBS2_PR="0") == expect("S2_TABLE_B1", 4)
+    assert name("S2_TABLE_B2") == expect("S2_TABLE_B2", 8)           # 1/3 normal (degree 5): classic kernel
     assert name("S2_TABLE_B4", DVBS2_V2="1", DVBS2_SOLO="1") == "ldpc_layered_kernel<8, packed, solo>"
     assert name("S2_TABLE_B4", DVBS2_V2="0", DVBS2_SOLO="0") == "ldpc_layered_kernel<8>"
     assert name("S2_TABLE_B11", DVBS2_V2="1", DVBS2_SOLO="1") == "ldpc_layered_kernel<32, packed>"  # no one-frame build above 128 VGPRs
