@@ -30,9 +30,6 @@
 #ifndef DVBS2_PR6_DIRECT
 #define DVBS2_PR6_DIRECT 1
 #endif
-#ifndef DVBS2_PR_PRETEST_AHEAD
-#define DVBS2_PR_PRETEST_AHEAD 0
-#endif
 
 namespace dvbs2 {
 
@@ -287,28 +284,6 @@ __global__ __launch_bounds__(kThreads, 6) void ldpc_layered_pr_kernel(
             const uint32_t* rec = recs + (size_t)i0 * RS;
             const int deg = (int)(rec[0] & 0xffu) + 2;
             uint32_t x = 0, z = 0;
-            if constexpr (DVBS2_PR_PRETEST_AHEAD == 2 || (DVBS2_PR_PRETEST_AHEAD == 1 && W1)) {
-            // Round 6: the two parity bytes that live in the message records (HBM / L2) are requested FIRST and together; edge by edge each was one
-            // round trip to memory in front of the next edge's LDS read.
-            const bool own_rec = i0 != q - 1, prev_rec = i0 != 0; // uniform
-            uint32_t wo = 0, wp = 0;
-            if (own_rec) wo = msg_base[((i0 + 1) * RW + PW) * kMsgStride + tid];  // own parity P[i0]
-            if (prev_rec) wp = msg_base[(i0 * RW + PW) * kMsgStride + tid];       // previous parity P[i0-1]
-            auto lds_entry = [&](int k) -> uint32_t {
-                const int a0 = tid + (int)rec[4 + 2 * k] - ((uint32_t)tid < rec[5 + 2 * k] ? 0 : kM);
-                return lds[a0];
-            };
-            for (int k = 0; k < deg - 2; k++) { const uint32_t v = lds_entry(k); x ^= v; z |= (v == 0x80u); }
-            {
-                const uint32_t v = own_rec ? wo >> 24 : lds_entry(deg - 2);
-                x ^= v; z |= (v == 0x80u);
-            }
-            {
-                uint32_t v = prev_rec ? wp >> 24 : lds_entry(deg - 1);
-                if (i0 == 0 && tid == 0) v = 0x81u; // check (0,0) has no previous parity
-                x ^= v; z |= (v == 0x80u);
-            }
-            } else
             for (int k = 0; k < deg; k++) {
                 uint32_t v;
                 if (k == deg - 2 && i0 != q - 1) v = msg_base[((i0 + 1) * RW + PW) * kMsgStride + tid] >> 24;       // own parity P[i0]
