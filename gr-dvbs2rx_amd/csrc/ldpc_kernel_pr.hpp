@@ -30,6 +30,14 @@
 #ifndef DVBS2_PR6_DIRECT
 #define DVBS2_PR6_DIRECT 1
 #endif
+// Round 6: the record accesses of the layer loop as (uniform pointer of the layer) + (per-lane byte offset, loop invariant), and `finished` passed through
+// v_readfirstlane (it is read from LDS, so the compiler took it -- and with it the index of the deferred store -- for divergent): the two v_mad_u64_u32 per layer
+// become scalar multiplies and one v_lshl_add_u64 each, the loop's own VALU instructions drop to nine per layer. Interleaved A/B x 3 (notes/r06_stamps/pr_scalar_base_ab.txt):
+// short 1/4 1070.3 -> 1132.3 k (+5.8 %), S2X short +5.7 %, medium 11/45 +4.8 %, 1/4 normal +5.2 %; two-dword records +0.6 ... +1.4 %. (The MUBUF form of the same idea,
+// a buffer descriptor per access, had LOST 2-4 % earlier in the round.)
+#ifndef DVBS2_PR_SADDR
+#define DVBS2_PR_SADDR 1
+#endif
 
 namespace dvbs2 {
 
@@ -190,6 +198,9 @@ __device__ __attribute__((noinline)) unsigned long long pr_sign_vectors(const ld
 
 // Records use the PR LDS layout: data entries as in the classic kernel; own parity of the last layer at K + j;
 // previous parity of layer 0 at K + (j + 359) mod 360 (S0 = K + 359, thr = 1).
+// record word at (uniform word pointer) + (per-lane BYTE offset, loop invariant): the form the global instructions take a scalar base for
+__device__ __forceinline__ uint32_t pr_ld(const uint32_t* sbase, uint32_t boff) { return *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(sbase) + boff); }
+__device__ __forceinline__ void pr_st(uint32_t* sbase, uint32_t boff, uint32_t v) { *reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(sbase) + boff) = v; }
 template <bool W1>
 __global__ __launch_bounds__(kThreads, 6) void ldpc_layered_pr_kernel(
     const uint32_t* __restrict__ recs, const int8_t* __restrict__ llr_in, uint8_t* __restrict__ state,
@@ -369,6 +380,10 @@ __global__ __launch_bounds__(kThreads, 6) void ldpc_layered_pr_kernel(
         if (finished && other_flags[1]) break;
 
         // ---- one update sweep ----
+#if DVBS2_PR_SADDR
+        finished = __builtin_amdgcn_readfirstlane((int)finished) != 0; // (uniform over the frame; read from LDS above)
+        const uint32_t roff = (uint32_t)row * 4u;
+#endif
         const bool work = !finished;
         uint32_t pre1[RW], pre2[RW]; // records of the next two layers for this row
         int carry = 0x80;
@@ -422,15 +437,26 @@ __global__ __launch_bounds__(kThreads, 6) void ldpc_layered_pr_kernel(
             const int own_in = (int)(pre1[PW] >> 24); // top byte of record i+1 = P[i] (not used by the last layer)
             if constexpr (kDeferStore) {
                 asm volatile("" ::: "memory"); __builtin_amdgcn_s_waitcnt(0x0f70); asm volatile("" ::: "memory"); // vmcnt(0), on every path
+#if DVBS2_PR_SADDR
+                if (pend_on) { // (pend_on: work && i > 0, the record of layer i - 1)
+#pragma unroll
+                    for (int w = 0; w < RW; w++) pr_st(mp - (RW - w) * kMsgStride, roff, pend[w]);
+                }
+#else
                 if (pend_on) {
                     uint32_t* pp = msg_base + (size_t)pend_i * RW * kMsgStride;
 #pragma unroll
                     for (int w = 0; w < RW; w++) pp[w * kMsgStride + row] = pend[w];
                 }
+#endif
             }
             if (work && i + 2 < q) {
 #pragma unroll
+#if DVBS2_PR_SADDR
+                for (int w = 0; w < RW; w++) pre2[w] = pr_ld(mp + (2 * RW + w) * kMsgStride, roff);
+#else
                 for (int w = 0; w < RW; w++) pre2[w] = mp[(2 * RW + w) * kMsgStride + row];
+#endif
             }
             uint32_t y6 = 0;
             bool have_y6 = false;
