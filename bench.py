@@ -357,14 +357,23 @@ def host_entry(np, torch, capi, LdpcDecoder, T, dev, local, N, out_bytes, nf, tr
                     max_trials=trials, group_size=G, max_frames=nf, device=local)
     host = {}
     for frames in sizes:
-        xh = noise_llr(torch, frames, N, dev, 12345).cpu().numpy()
-        for mode in ("pageable", "registered"):
-            bits_h = np.empty((frames, out_bytes), np.uint8); ret_h = np.empty((frames + G - 1) // G, np.int32)
-            if mode == "registered":  # the caller page-locked its buffers once (dvbs2_host_register)
-                for a in (xh, bits_h, ret_h):
-                    capi.check(capi.lib.dvbs2_host_register(a.ctypes.data, a.nbytes))
+        xp = noise_llr(torch, frames, N, dev, 12345).cpu().numpy()
+        for mode in ("pageable", "page_locked"):
+            # page_locked: the caller's buffers are driver-allocated page-locked memory (dvbs2_host_alloc = hipHostMalloc), what a GNU Radio custom
+            # buffer would be. (Until round 6 this leg registered numpy's heap memory with dvbs2_host_register: on the round's boxes -- Linux 6.18,
+            # transparent_hugepage=always -- the D2H copy into such a registration faulted intermittently, "write access to a read-only page".)
+            hb = []
+            if mode == "page_locked":
+                from dvbs2rx_amd import HostBuffer
+                hb = [HostBuffer(xp.shape, np.int8), HostBuffer((frames, out_bytes), np.uint8), HostBuffer(((frames + G - 1) // G,), np.int32)]
+                xh, bits_h, ret_h = (h.array for h in hb)
+                xh[...] = xp
+            else:
+                xh = xp; bits_h = np.empty((frames, out_bytes), np.uint8); ret_h = np.empty((frames + G - 1) // G, np.int32)
             call = lambda: capi.check(capi.lib.dvbs2_ldpc_decode(d._h, xh.ctypes.data, frames, trials, capi.OM_MESSAGE,
                                                                  bits_h.ctypes.data, None, ret_h.ctypes.data))
+            if os.environ.get("BENCH_TRACE"):
+                print(f"[bench]   host_entry {frames} {mode} x {xh.ctypes.data:#x} bits {bits_h.ctypes.data:#x}+{bits_h.nbytes:#x} ret {ret_h.ctypes.data:#x}", file=sys.stderr, flush=True)
             call()
             if shard is not None:
                 shard.barrier_sync()
@@ -374,6 +383,8 @@ def host_entry(np, torch, capi, LdpcDecoder, T, dev, local, N, out_bytes, nf, tr
             th = (time.perf_counter() - t0) / steps2
             if shard is not None:
                 shard.barrier_sync()
+            if os.environ.get("BENCH_TRACE"):
+                print(f"[bench]   host_entry {frames} {mode}: host calls done, resident run", file=sys.stderr, flush=True)
             dx = torch.from_numpy(xh).to(dev); db = torch.empty((frames, out_bytes), dtype=torch.uint8, device=dev)
             fnr = lambda: d.work_device(dx.data_ptr(), frames, db.data_ptr(), 0, 0, stream)
             fnr(); torch.cuda.synchronize(); t0 = time.perf_counter()
@@ -387,10 +398,9 @@ def host_entry(np, torch, capi, LdpcDecoder, T, dev, local, N, out_bytes, nf, tr
                                         # bytes the call moves over the link per second of the call (in + out): the rate the decode
                                         # CONSUMES, not the link's capacity -- that is `host_link`
                                         "link_gbs_consumed": frames * (N + out_bytes + 4.0 / G) / th / 1e9}
-            if mode == "registered":
-                for a in (xh, bits_h, ret_h):
-                    capi.check(capi.lib.dvbs2_host_unregister(a.ctypes.data))
-            del dx, db
+            del dx, db, xh, bits_h, ret_h
+            for h in hb:
+                h.free()
     fb = d.fallback_rounds
     d.close()
     return host, fb
@@ -446,7 +456,7 @@ def host_pipelined(np, torch, capi, LdpcDecoder, dev, local, N, out_bytes, nf, t
         same = bool(torch.equal(hb[0], hb[1]) and torch.equal(hb[0], db[0].cpu()) and torch.equal(hr[0], dr[0].cpu()))
         if not same:
             raise RuntimeError("PARITY FAILURE: pipelined host feed differs from the device entry")
-        sync = sync_calls.get(f"{frames}_registered", {})
+        sync = sync_calls.get(f"{frames}_page_locked", {})
         out[str(frames)] = {"frames_per_call": frames, "calls": ncalls, "frames_per_s": frames * ncalls / tp, "resident_frames_per_s": frames / tr,
                             "frac_of_resident": (frames * ncalls / tp) / (frames / tr), "same_results": same,
                             "synchronous_page_locked_frac_of_resident": sync.get("frac_of_resident"),
@@ -531,12 +541,16 @@ def chain_host_entry(np, torch, capi, FecChain, dev, local, nf, trials, G, strea
             t0 = time.perf_counter(); fnr(); torch.cuda.synchronize(); trs.append(time.perf_counter() - t0)
         tr = sorted(trs)[len(trs) // 2]
         want_msg, want_corr = d_msg.cpu().numpy(), d_corr.cpu().numpy()
-        for mode in ("pageable", "registered"):
-            msg_h = np.empty((frames, mb), np.uint8); ret_h = np.empty((frames + G - 1) // G, np.int32); corr_h = np.empty(frames, np.int32)
-            bufs = (sh, msg_h, ret_h, corr_h)
-            if mode == "registered":
-                for a in bufs:
-                    capi.check(capi.lib.dvbs2_host_register(a.ctypes.data, a.nbytes))
+        sp = sh
+        for mode in ("pageable", "page_locked"):
+            hb = []
+            if mode == "page_locked":  # driver-allocated page-locked buffers of the caller (dvbs2_host_alloc; see host_entry)
+                from dvbs2rx_amd import HostBuffer
+                hb = [HostBuffer(sp.shape, sp.dtype), HostBuffer((frames, mb), np.uint8), HostBuffer(((frames + G - 1) // G,), np.int32), HostBuffer((frames,), np.int32)]
+                sh, msg_h, ret_h, corr_h = (h.array for h in hb)
+                sh[...] = sp
+            else:
+                sh = sp; msg_h = np.empty((frames, mb), np.uint8); ret_h = np.empty((frames + G - 1) // G, np.int32); corr_h = np.empty(frames, np.int32)
             call = lambda: ch.work_host_ptr(sh.ctypes.data, frames, n0h.ctypes.data, 1, msg_h.ctypes.data, ret_h.ctypes.data, corr_h.ctypes.data)
             call()
             ths = []
@@ -549,9 +563,9 @@ def chain_host_entry(np, torch, capi, FecChain, dev, local, nf, trials, G, strea
                 "frames_per_call": frames, "frames_per_s": frames / th, "ms_per_call": th * 1e3, "ms_per_call_runs": [t * 1e3 for t in ths],
                 "resident_frames_per_s": frames / tr, "frac_of_resident": tr / th, "link_gbs_consumed": frames * bytes_per_frame / th / 1e9,
                 "frac_of_link_bound": (frames / th) / res["link_bound_frames_per_s"] if res["link_bound_frames_per_s"] else None}
-            if mode == "registered":
-                for a in bufs:
-                    capi.check(capi.lib.dvbs2_host_unregister(a.ctypes.data))
+            del sh, msg_h, ret_h, corr_h
+            for h in hb:
+                h.free()
         del d_msg, d_ret, d_corr
     ch.close()
     # two handles x page-locked buffers of the caller, device-pointer ABI
@@ -591,7 +605,7 @@ def chain_host_entry(np, torch, capi, FecChain, dev, local, nf, trials, G, strea
         for _ in range(3):
             t0 = time.perf_counter(); run_pipe(); tps.append(time.perf_counter() - t0)
         tp = sorted(tps)[1]
-        sync = res["calls"].get(f"{frames}_registered", {})
+        sync = res["calls"].get(f"{frames}_page_locked", {})
         same = bool(torch.equal(hm[0], hm[1]))
         pipe[str(frames)] = {"frames_per_call": frames, "calls": ncalls, "frames_per_s": frames * ncalls / tp,
                              "frac_of_resident": (frames * ncalls / tp) / sync.get("resident_frames_per_s", float("nan")),
@@ -628,6 +642,10 @@ def main():
     from dvbs2rx_amd import Demapper, FecChain, LdpcDecoder, capi, get_fec_info, ldpc_table_info, shard
 
     world, rank, local = shard.init_from_env()  # nccl (= RCCL) rendezvous when WORLD_SIZE > 1
+
+    def trace(stage):  # BENCH_TRACE=1: stage names on stderr as they start (a GPU fault aborts the process without a Python traceback)
+        if os.environ.get("BENCH_TRACE"):
+            print(f"[bench] {stage}", file=sys.stderr, flush=True)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -682,6 +700,7 @@ def main():
         sy = txd + float(np.sqrt(n0v_ / 2.0)) * torch.randn(txd.shape, generator=g, device=dev)
         return sy, n0v_, msg0_
 
+    trace("device_copy")
     device_copy = device_copy_bandwidth(torch, dev)  # first: the limiter objects compare the fabric-side rate with it
     roofline.copy_gbs = device_copy["read_plus_write_gbs"]
     shader_clock = None
@@ -694,6 +713,7 @@ def main():
         roofline.clock_ghz = ghz.value
     except Exception as e:  # (diagnostic only)
         shader_clock = {"error": str(e)}
+    trace("headline input + gate")
     llr = noise_llr(torch, nf, N, dev, 12345 + rank) if args.input == "noise" else awgn_llr(4242 + rank)
     d_bits = torch.empty((nf, out_bytes), dtype=torch.uint8, device=dev)
     d_ret = torch.empty((nf + G - 1) // G, dtype=torch.int32, device=dev)
@@ -702,6 +722,7 @@ def main():
     def step():
         dec.work_device(llr.data_ptr(), nf, d_bits.data_ptr(), 0, d_ret.data_ptr(), stream)
 
+    trace("headline timed region")
     for _ in range(args.warmup):
         step()
     dec.profile(True)  # HIP events around the dominant kernel, on its launch stream
@@ -742,6 +763,7 @@ def main():
     configs = {}
 
     def ldpc_only(name, tbl, frames, trials, label):
+        trace(name)
         ti = ldpc_table_info(tbl)
         d = LdpcDecoder(table=tbl, message_bits=ti["K"], outputmode=capi.OM_MESSAGE, max_trials=trials, group_size=G,
                         max_frames=frames, device=local)
@@ -759,6 +781,7 @@ def main():
         d.close()
 
     def llr_chain(name, rate, frames, trials, label):
+        trace(name)
         fi = get_fec_info(capi.STANDARD_DVBS2, capi.FECFRAME_NORMAL, rate)
         ti = ldpc_table_info(fi["table"])
         ch = FecChain(rate=rate, group_size=G, max_frames=frames, max_trials=trials, device=local, from_llr=True)
@@ -786,6 +809,7 @@ def main():
 
     if not args.no_configs:
         if "config3" in want:
+            trace("config3")
             fi = get_fec_info(capi.STANDARD_DVBS2, capi.FECFRAME_NORMAL, "C3_4")
             ch = FecChain(rate="C3_4", constellation=capi.MOD_8PSK, group_size=G, max_frames=nf, max_trials=args.trials, device=local)
             g = torch.Generator(device=dev); g.manual_seed(777 + rank)
@@ -831,9 +855,11 @@ def main():
         extras = [c for c in args.only.split(",") if c] or ["config2_awgn", "config3_awgn", "config4_awgn", "config2_host", "config3_host", "demap",
                                                             "device_copy", "host_link", "mapping_ceiling"]
         if "host_link" in extras or "config3_host" in extras:
+            trace("host_link")
             out["host_link"] = host_link_bandwidth(capi, local)
         bl50 = ldpc_bytes(N, out_bytes, info["links_total"], args.trials)
         if "config2_awgn" in extras:
+            trace("config2_awgn")
             d = LdpcDecoder(standard=capi.STANDARD_DVBS2, framesize=capi.FECFRAME_NORMAL, rate="C1_2", outputmode=capi.OM_MESSAGE,
                             max_trials=args.trials, group_size=G, max_frames=nf, device=local)
             x = awgn_llr(4242)
@@ -864,6 +890,7 @@ def main():
             # call i + 2 is enqueued): what a double-buffering block does. The tail of a launch -- no workgroup left to dispatch while
             # its last groups finish, ~0.9 ms of a 14 ms call -- then runs under the next call's first groups. Same bits, and the
             # group-synchronous stop has to survive two sweep kernels sharing the GPU (fallback rounds reported).
+            trace("config2_awgn pipelined")
             d2 = LdpcDecoder(standard=capi.STANDARD_DVBS2, framesize=capi.FECFRAME_NORMAL, rate="C1_2", outputmode=capi.OM_MESSAGE,
                              max_trials=args.trials, group_size=G, max_frames=nf, device=local)
             hs = [d, d2]
@@ -882,6 +909,7 @@ def main():
             d2.close()
             d.close(); del x
         if "config3_awgn" in extras:
+            trace("config3_awgn")
             # SURVEY 8(d) config 3 on the input it names first: valid BCH o LDPC codewords, 8PSK-mapped through the inverse of the block's
             # de-interleaver (lib/xfecframe_demapper_cb_impl.cc:162-176: column c of the 21600 x 3 matrix = LLRs c * 21600 ...), AWGN at
             # Es/N0 = 8.5 dB, N0 supplied per call (:148; the loopback of examples/dvbs2_fec_ber.grc:809-830). Whole-batch gate: demapper
@@ -922,6 +950,7 @@ def main():
                 "bch_corrections_histogram": {str(int(a)): int(b) for a, b in zip(cv.tolist(), cc.tolist())},
                 "roofline": roofline(ch, bl, nf),
                 "frac_of_proportional_rate": (val / (c3 * args.trials / max(mean_upd, 1e-9))) if c3 else None}
+            trace("config3_awgn pipelined")
             ch2 = FecChain(rate="C3_4", constellation=capi.MOD_8PSK, group_size=G, max_frames=nf, max_trials=args.trials, device=local)
             hs = [ch, ch2]
             ms2 = [msg, torch.empty_like(msg)]
@@ -935,6 +964,7 @@ def main():
             ch2.close()
             ch.close(); del syms
         if "config4_awgn" in extras:
+            trace("config4_awgn")
             # config 4 at ITS operating point. SURVEY 8(d) names Es/N0 = -1.8 dB; with the demapper's LLR scale (mean |LLR| ~ 1.3, offset
             # beta = 1) the GENUINE reference does not converge there within 25 updates (ret -1 down to -0.5 dB, 19-22 updates at 0.0 dB,
             # 13-14 at 0.5 dB; measured with oracle/_ref in the build container): 0.5 dB, as config 2 runs 0.5 dB above ITS threshold.
@@ -962,6 +992,7 @@ def main():
                 "failed_groups": int((r < 0).sum().item()),
                 "roofline": roofline(d, ldpc_bytes(ti["N"], d.out_bytes, ti["links_total"], mean_upd), fr4),
                 "frac_of_proportional_rate": (val / (c4 * tr4 / max(mean_upd, 1e-9))) if c4 else None}
+            trace("config4_awgn pipelined")
             d2 = LdpcDecoder(table=tbl4, message_bits=ti["K"], outputmode=capi.OM_MESSAGE, max_trials=tr4, group_size=G, max_frames=fr4, device=local)
             hs = [d, d2]
             bs = [b, torch.empty_like(b)]
@@ -976,6 +1007,7 @@ def main():
             d2.close()
             d.close(); del x
         if "config2_host" in extras:
+            trace("config2_host")
             host, fb = host_entry(np, torch, capi, LdpcDecoder, T, dev, local, N, out_bytes, nf, args.trials, G, stream, steps2, (nf, 512))
             pipe_host = host_pipelined(np, torch, capi, LdpcDecoder, dev, local, N, out_bytes, nf, args.trials, G, (nf, 512), host)
             configs["config2_host"] = {"pipelined": pipe_host,
@@ -984,6 +1016,7 @@ def main():
                                        "value": host[f"{nf}_pageable"]["frames_per_s"], "calls": host, "fallback_rounds": fb,
                                        "step_frac_of_hbm_peak": bl50 * host[f"{nf}_pageable"]["frames_per_s"] / 1e9 / HBM_PEAK_GBS}
         if "config3_host" in extras:
+            trace("config3_host")
             # SURVEY 8(b) fused entry from HOST buffers + 8(d) "end-to-end incl. H2D / D2H": dvbs2_chain_decode on config 3's two inputs
             link = out["host_link"]["hipHostRegister_1_stream"]["h2d"]
             g = torch.Generator(device=dev); g.manual_seed(777 + rank)
@@ -998,13 +1031,15 @@ def main():
             configs["config3_host"] = {
                 "workload": "dvbs2_chain_decode (HOST symbols in, HOST message bytes out: H2D + demapper + LDPC (S2_TABLE_B7) + BCH + D2H per synchronous call), "
                             f"8PSK 3/4 normal, cap {args.trials}; never the headline value", "unit": "frames/s",
-                "value": opp["calls"][f"{nf}_registered"]["frames_per_s"], "host_link_h2d_gbs": link, "worst_case": worst, "operating_point": opp}
+                "value": opp["calls"][f"{nf}_page_locked"]["frames_per_s"], "host_link_h2d_gbs": link, "worst_case": worst, "operating_point": opp}
         if "demap" in extras:
+            trace("demap")
             out["demap"] = demap_entry(np, torch, capi, Demapper, T, dev, local, nf, stream, roofline.copy_gbs)
         if "device_copy" in extras:
             out["device_copy"] = device_copy
             out["roofline"]["frac_of_measured_copy"] = out["roofline"]["achieved"] / out["device_copy"]["read_plus_write_gbs"]
         if "mapping_ceiling" in extras:
+            trace("mapping_ceiling")
             # What THIS thread-per-check-row mapping does when nothing orders the rows: S2X_TABLE_B3 (9/20 normal) is B4's hazard-free
             # sibling -- the same check degree 7, the same kernel build, 99 layers, no layer with two entries of one group. Its
             # edge-update rate, measured in this run, projected onto B4's edge count, is the rate B4 would have without its 8 hazard
@@ -1029,7 +1064,7 @@ def main():
         # beside the resident `value`.
         host, fb = host_entry(np, torch, capi, LdpcDecoder, T, dev, local, N, out_bytes, nf, args.trials, G, stream, steps2, (nf,), shard)
         feed = {}
-        for mode in ("pageable", "registered"):
+        for mode in ("pageable", "page_locked"):
             per = shard.gather_over_ranks(host[f"{nf}_{mode}"]["frames_per_s"], device=dev)
             res = shard.gather_over_ranks(host[f"{nf}_{mode}"]["resident_frames_per_s"], device=dev)
             feed[mode] = {"per_rank_frames_per_s": per, "sum_frames_per_s": sum(per), "sum_resident_frames_per_s": sum(res),

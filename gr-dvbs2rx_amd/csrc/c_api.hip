@@ -4,6 +4,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <sys/mman.h>
 #include <new>
 #include <string>
 #include <utility>
@@ -89,6 +90,21 @@ int dvbs2_host_register(void* p, size_t bytes)
 }
 
 int dvbs2_host_is_page_locked(const void* p, size_t bytes) { return host_range_page_locked(p, bytes) ? 1 : 0; }
+
+int dvbs2_host_alloc(void** p, size_t bytes)
+{
+    if (!p || !bytes) return fail(DVBS2_EINVAL, "bad argument");
+    *p = nullptr;
+    HCHK(hipHostMalloc(p, bytes, hipHostMallocDefault));
+    return DVBS2_OK;
+}
+
+int dvbs2_host_free(void* p)
+{
+    if (!p) return DVBS2_OK;
+    HCHK(hipHostFree(p));
+    return DVBS2_OK;
+}
 
 int dvbs2_host_unregister(void* p)
 {
@@ -397,13 +413,21 @@ int dvbs2_measure_host_copy(int device, size_t bytes, int n_streams, int kind, d
     hipStream_t st[16] = {};
     hipEvent_t e0 = nullptr, e1 = nullptr, done[16] = {};
     int rc = DVBS2_OK;
+    bool registered = false;
     auto body = [&]() -> int {
         if (kind == 0) HCHK(hipHostMalloc(&host, bytes));
-        else {
+        else if (kind == 1) {
+            // a mapping of its own for the registration (whole pages nothing else lives in; shared anonymous memory: no copy-on-write, no
+            // anonymous huge pages under it) -- see dvbs2_host_alloc in the header for why heap memory is not registered here any more
+            host = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED | MAP_ANONYMOUS, -1, 0);
+            if (host == MAP_FAILED) { host = nullptr; return fail(DVBS2_EDEVICE, "out of host memory"); }
+            std::memset(host, 1, bytes);
+            HCHK(hipHostRegister(host, bytes, hipHostRegisterDefault));
+            registered = true;
+        } else {
             host = std::malloc(bytes);
             if (!host) return fail(DVBS2_EDEVICE, "out of host memory");
             std::memset(host, 1, bytes);
-            if (kind == 1) HCHK(hipHostRegister(host, bytes, hipHostRegisterDefault));
         }
         HCHK(hipMalloc(&dev, bytes));
         for (int i = 0; i < n_streams; i++) { HCHK(hipStreamCreateWithFlags(&st[i], hipStreamNonBlocking)); HCHK(hipEventCreateWithFlags(&done[i], hipEventDisableTiming)); }
@@ -436,7 +460,11 @@ int dvbs2_measure_host_copy(int device, size_t bytes, int n_streams, int kind, d
     if (e0) (void)hipEventDestroy(e0);
     if (e1) (void)hipEventDestroy(e1);
     if (dev) (void)hipFree(dev);
-    if (host) { if (kind == 0) (void)hipHostFree(host); else { if (kind == 1) (void)hipHostUnregister(host); std::free(host); } }
+    if (host) {
+        if (kind == 0) (void)hipHostFree(host);
+        else if (kind == 1) { if (registered) (void)hipHostUnregister(host); (void)munmap(host, bytes); }
+        else std::free(host);
+    }
     return rc;
     API_CATCH
 }

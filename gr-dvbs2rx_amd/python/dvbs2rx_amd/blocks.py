@@ -15,7 +15,7 @@ from .capi import lib, check
 
 __all__ = ["get_fec_info", "rate_id", "LdpcDecoder", "BchDecoder", "Demapper", "FecChain", "BbDeheader", "ldpc_table_info", "ldpc_layer_info",
            "ldpc_table_names", "bb_descramble_sequence", "PlPayload",
-           "pl_scrambling_rn"]
+           "pl_scrambling_rn", "HostBuffer"]
 
 DEFAULT_TRIALS = 25  # reference lib/ldpc_decoder_bb_impl.cc:391
 
@@ -47,6 +47,37 @@ def bb_descramble_sequence(n_bytes):
     seq = np.zeros(n_bytes, np.uint8)
     check(lib.dvbs2_bb_descramble_sequence(seq.ctypes.data, n_bytes))
     return seq
+
+
+class HostBuffer:
+    """A page-locked host buffer allocated by the driver (dvbs2_host_alloc -> hipHostMalloc) with a numpy view: what a caller of the
+    host-pointer entry points should hand over where it can choose its memory (include/dvbs2_fec_hip.h). `array` stays valid until
+    free() / the object is dropped."""
+
+    def __init__(self, shape, dtype):
+        self.array = None
+        self._p = C.c_void_p()
+        dt = np.dtype(dtype)
+        n = int(np.prod(shape)) * dt.itemsize
+        check(lib.dvbs2_host_alloc(C.byref(self._p), max(n, 1)))
+        self.nbytes = n
+        self.array = np.frombuffer((C.c_char * max(n, 1)).from_address(self._p.value), dtype=dt, count=int(np.prod(shape))).reshape(shape)
+
+    @property
+    def ptr(self):
+        return self._p.value
+
+    def free(self):
+        if self._p:
+            self.array = None
+            lib.dvbs2_host_free(self._p)
+            self._p = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
 
 
 def ldpc_table_names():

@@ -45,6 +45,8 @@ SYMBOLS = {
     "dvbs2_host_register": (_i, [_vp, C.c_size_t]),
     "dvbs2_host_unregister": (_i, [_vp]),
     "dvbs2_host_is_page_locked": (_i, [_vp, C.c_size_t]),
+    "dvbs2_host_alloc": (_i, [C.POINTER(_vp), C.c_size_t]),
+    "dvbs2_host_free": (_i, [_vp]),
     "dvbs2_get_fec_info": (_i, [_i, _i, _i, C.POINTER(FecInfo)]),
     "dvbs2_rate_name": (C.c_char_p, [_i]),
     "dvbs2_rate_from_name": (_i, [C.c_char_p]),

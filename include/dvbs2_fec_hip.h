@@ -51,7 +51,8 @@ int dvbs2_device_count(void);
 
 /* Page-lock a host buffer that the block hands to the plain (host-pointer) entry points again and again -- e.g. a GNU
  * Radio input buffer, once, at start() -- so that the transfers run at PCIe speed and asynchronously (pageable memory
- * goes through a staging copy at a fraction of it and blocks the calling thread). Optional; undo before freeing.
+ * goes through a staging copy at a fraction of it and blocks the calling thread). Optional; undo before freeing. Register whole
+ * mappings of their own (an mmap'ed buffer), not pieces of the malloc heap; where the caller can choose its memory: dvbs2_host_alloc below.
  * dvbs2_ldpc_decode() also lands its results directly in bits_out / llr_out / ret when THOSE are page-locked (registered here or
  * allocated with hipHostMalloc) instead of in pinned buffers of the handle that it copies out afterwards -- the WHOLE output range has
  * to lie inside ONE registration / allocation visible to the handle's device (a range that spans two registrations with a pageable
@@ -61,6 +62,14 @@ int dvbs2_device_count(void);
  * DVBS2_EINVAL. */
 int dvbs2_host_register(void* p, size_t bytes);
 int dvbs2_host_unregister(void* p);
+/* Page-locked host memory allocated BY THE DRIVER (hipHostMalloc / hipHostFree) for callers that do not link HIP themselves: what a
+ * GNU Radio >= 3.10 custom buffer allocator or a block's own staging buffer should use where it can choose. Preferred
+ * over dvbs2_host_register on ordinary malloc'ed memory: a registration mirrors pages the kernel's memory management still owns
+ * (transparent huge pages, compaction, fork), and round 6 saw a GPU write into registered heap memory of a long-running process fault
+ * ("write access to a read-only page", Linux 6.18 with transparent_hugepage=always, intermittent); driver-allocated memory is not
+ * subject to that. *p is 4096-byte aligned. (reference side: the item buffers of lib/ldpc_decoder_bb_impl.cc:394-455 / bch_decoder_bb_impl.cc:84-117) */
+int dvbs2_host_alloc(void** p, size_t bytes);
+int dvbs2_host_free(void* p);
 /* 1 when [p, p + bytes) lies inside ONE page-locked allocation / registration as the runtime records it (the test the host-buffer
  * entry applies to the caller's buffers before it lets the copy engine address them directly), else 0. Diagnostics and tests. */
 int dvbs2_host_is_page_locked(const void* p, size_t bytes);
@@ -138,7 +147,7 @@ int dvbs2_ldpc_profile(dvbs2_ldpc_t* h, int enable, double* total_ms, int* launc
  * launches (results identical). Zero in normal operation -- tests and bench.py assert it. */
 int dvbs2_ldpc_fallback_rounds(const dvbs2_ldpc_t* h);
 /* Diagnostics. Plain hipMemcpyAsync rate of this box's host link, GB/s, best of two timed repetitions: `bytes` split evenly over
- * n_streams (1..16) concurrent streams, host memory kind 0 = hipHostMalloc, 1 = malloc + hipHostRegister (what dvbs2_host_register
+ * n_streams (1..16) concurrent streams, host memory kind 0 = hipHostMalloc, 1 = a mapping of its own + hipHostRegister (what dvbs2_host_register
  * does to a caller's buffer), 2 = pageable malloc. Beside the host-entry rates of bench.py (config2_host): is the link or the
  * pipeline what limits dvbs2_ldpc_decode? (reference call site that hands over host buffers: lib/ldpc_decoder_bb_impl.cc:406-449) */
 int dvbs2_measure_host_copy(int device, size_t bytes, int n_streams, int kind, double* h2d_gbs, double* d2h_gbs);

@@ -2,6 +2,7 @@
 packed bits and per-group return values. Checkers: oracle/liboracle.so (plain-C restatement) and, when the
 prebuilt oracle/_ref travelled with the repo, the genuine reference decoders (AVX2 batch = 32 frames,
 generic batch = 16 frames)."""
+import ctypes as C
 import os
 
 import numpy as np
@@ -675,9 +676,17 @@ def test_host_entry_large_odd_group_with_registered_buffers():
     llr, _ = T.llr_codeword_awgn(table, nf, 91, amp=5, sigma=5.0)
     llr[5] = T.llr_noise(1, N, 3)[0]
     guard = 4096                                           # canaries behind every caller buffer
-    xin = np.full(llr.size + guard, 0x55, np.int8); xin[:llr.size] = llr.ravel()
-    bits = np.full(nf * (K // 8) + guard, 0xA5, np.uint8)
-    ret = np.full(2 + guard // 4, 0x7A7A7A7A, np.int32)
+    import mmap
+
+    def shared(n, dtype, fill):
+        # the caller's registered buffers are mappings of their own (MAP_SHARED | MAP_ANONYMOUS: whole pages that nothing else lives in, no
+        # copy-on-write, no anonymous huge pages) -- registering numpy HEAP memory is what faulted intermittently in bench.py (include/dvbs2_fec_hip.h)
+        a = np.frombuffer(mmap.mmap(-1, n * np.dtype(dtype).itemsize), dtype=dtype)
+        a[...] = fill
+        return a
+    xin = shared(llr.size + guard, np.int8, 0x55); xin[:llr.size] = llr.ravel()
+    bits = shared(nf * (K // 8) + guard, np.uint8, 0xA5)
+    ret = shared(2 + guard // 4, np.int32, 0x7A7A7A7A)
     for a in (xin, bits, ret):
         capi.check(capi.lib.dvbs2_host_register(a.ctypes.data, a.nbytes))
     dec = LdpcDecoder(table=table, message_bits=K, group_size=G, max_frames=2 * nf, max_trials=cap, outputmode=capi.OM_MESSAGE)
@@ -695,6 +704,37 @@ def test_host_entry_large_odd_group_with_registered_buffers():
     want, wret = T.oracle_ldpc_decode(table, llr[:G], G, cap)
     assert ret[0] == wret[0] and np.array_equal(bits[:G * (K // 8)].reshape(G, K // 8), T.pack_bits(want, K))
     dec.close()
+
+
+def test_host_entry_with_driver_allocated_buffers():
+    """dvbs2_host_alloc / dvbs2_host_free (hipHostMalloc'ed caller buffers, what include/dvbs2_fec_hip.h recommends over registering malloc'ed
+    memory): the range is recognised as page-locked, the host-pointer entry lands its results in it directly and they equal the device entry's."""
+    import torch
+    from dvbs2rx_amd import HostBuffer
+    table, G, cap, nf = "S2_TABLE_C1", 32, 6, 640
+    N, K, _, _ = T.ldpc_info(table)
+    llr, _ = T.llr_codeword_awgn(table, nf, 93, amp=5, sigma=5.2)
+    hx, hb, hr = HostBuffer((nf, N), np.int8), HostBuffer((nf, K // 8), np.uint8), HostBuffer((nf // G,), np.int32)
+    assert hx.ptr % 4096 == 0
+    for h in (hx, hb, hr):
+        assert capi.lib.dvbs2_host_is_page_locked(h.ptr, h.nbytes) == 1
+    assert capi.lib.dvbs2_host_is_page_locked(hb.ptr, hb.nbytes + (1 << 30)) == 0  # past the end of the allocation
+    hx.array[...] = llr; hb.array[...] = 0xA5; hr.array[...] = 0x7A7A7A7A
+    dec = LdpcDecoder(table=table, message_bits=K, group_size=G, max_frames=nf, max_trials=cap, outputmode=capi.OM_MESSAGE)
+    capi.check(capi.lib.dvbs2_ldpc_decode(dec._h, hx.ptr, nf, cap, capi.OM_MESSAGE, hb.ptr, None, hr.ptr))
+    d_in = torch.from_numpy(llr).cuda()
+    d_bits = torch.empty((nf, K // 8), dtype=torch.uint8, device="cuda")
+    d_ret = torch.empty(nf // G, dtype=torch.int32, device="cuda")
+    dec.work_device(d_in.data_ptr(), nf, d_bits.data_ptr(), 0, d_ret.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    assert np.array_equal(hb.array, d_bits.cpu().numpy()) and hr.array.tolist() == d_ret.cpu().tolist()
+    want, wret = T.oracle_ldpc_decode(table, llr[:G], G, cap)
+    assert hr.array[0] == wret[0] and np.array_equal(hb.array[:G], T.pack_bits(want, K))
+    dec.close()
+    for h in (hx, hb, hr):
+        h.free()
+    assert capi.lib.dvbs2_host_free(None) == capi.OK
+    p = C.c_void_p()
+    assert capi.lib.dvbs2_host_alloc(C.byref(p), 0) == capi.EINVAL and capi.lib.dvbs2_host_alloc(None, 16) == capi.EINVAL
 
 
 def test_misaligned_device_pointers_are_refused():

@@ -121,7 +121,7 @@ def test_bench_n2_branch_runs_on_one_gpu():
     c5 = d["configs"]["config5"]
     assert c5["frames_total"] == 2 * c5["frames_per_gpu"] and c5["value"] > 0 and c5["roofline"]["kernel"].startswith("ldpc_layered_kernel<32")
     host = d["configs"]["config2_host"]["ranks"]
-    for mode in ("pageable", "registered"):
+    for mode in ("pageable", "page_locked"):
         assert len(host[mode]["per_rank_frames_per_s"]) == 2 and all(v > 0 for v in host[mode]["per_rank_frames_per_s"])
     assert d["fallback_rounds"] == 0
 
