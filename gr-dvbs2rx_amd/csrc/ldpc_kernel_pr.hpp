@@ -27,17 +27,11 @@
 // Round 6: the degree-3 / 4 node of the one-dword-record kernel takes the minimum over the OTHER links directly (see check_node_pr6). Interleaved A/B against
 // "two smallest + select" (three repetitions, gpurun_out/r6m): short 1/4 1059.8 -> 1074.1 k (+1.3 %), S2X short 1220 -> 1232 k, medium 1/5 and 11/45 +1.0 / +1.1 %,
 // 1/4 normal and S2X 2/9 normal +0.9 / +1.2 %; the kernel's other tables (two-dword records) 1.000 / 1.001.
-#ifndef DVBS2_PR6_DIRECT
-#define DVBS2_PR6_DIRECT 1
-#endif
 // Round 6: the record accesses of the layer loop as (uniform pointer of the layer) + (per-lane byte offset, loop invariant), and `finished` passed through
 // v_readfirstlane (it is read from LDS, so the compiler took it -- and with it the index of the deferred store -- for divergent): the two v_mad_u64_u32 per layer
 // become scalar multiplies and one v_lshl_add_u64 each, the loop's own VALU instructions drop to nine per layer. Interleaved A/B x 3 (notes/r06_stamps/pr_scalar_base_ab.txt):
 // short 1/4 1070.3 -> 1132.3 k (+5.8 %), S2X short +5.7 %, medium 11/45 +4.8 %, 1/4 normal +5.2 %; two-dword records +0.6 ... +1.4 %. (The MUBUF form of the same idea,
 // a buffer descriptor per access, had LOST 2-4 % earlier in the round.)
-#ifndef DVBS2_PR_SADDR
-#define DVBS2_PR_SADDR 1
-#endif
 
 namespace dvbs2 {
 
@@ -101,22 +95,17 @@ __device__ __forceinline__ uint32_t check_node_pr6(uint8_t* __restrict__ lds, co
     const bool last_valid = !LAYER0 || jj != 0;
     int spare = 0x80;
     int inp[DEG], mg[DEG];
-    int min0 = 127, min1 = 127, signs = 0;
+    int signs = 0;
 #pragma unroll
     for (int k = 0; k < DEG; k++) {
         const int mb = (int)((x >> (6 * k)) & 0x3fu) + 96; // field = m + 32 -> offset-binary byte m + 128
         int d = min(max(Lb[k] - mb, -128), 127);
-#if DVBS2_PR6_DIRECT
         int mag = (int)__builtin_amdgcn_sad_u16((uint32_t)Lb[k], (uint32_t)mb, 0u); // |Lb - mb| in [0, 255]
-#else
-        int mag = mag_raw(Lb[k], mb);
-#endif
         if (LAYER0 && k == DEG - 1) { d = last_valid ? d : 0; mag = last_valid ? mag : kMagAbsent; }
         inp[k] = d; mg[k] = mag;
         signs ^= d;
     }
     __builtin_amdgcn_s_setprio(1);
-#if DVBS2_PR6_DIRECT
     // Degree 3 / 4: the minimum over the OTHER links directly (R3 + R5's selection in one): v_min3_u32 of the other raw |Lb - mb| and 127
     // (R2's qabs bound), then one saturating subtract of the offset -- 3 half-rate + 3 full-rate instructions at degree 3 and 6 + 4 at degree 4,
     // against 7 + 4 and 10 + 5 for "two smallest, clamp both, select per link".
@@ -132,21 +121,11 @@ __device__ __forceinline__ uint32_t check_node_pr6(uint8_t* __restrict__ lds, co
         oth[2] = (int)vmin3_u32((uint32_t)mg[3], m01, 127u);
         oth[3] = (int)vmin3_u32((uint32_t)mg[2], m01, 127u);
     }
-    (void)min0; (void)min1;
-#else
-    two_smallest<DEG>(mg, min0, min1);
-    min0 = clamp_mag(min0); min1 = clamp_mag(min1);
-    const int s01 = min0 + min1;
-#endif
     uint32_t y = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         if (k < DEG) {
-#if DVBS2_PR6_DIRECT
             const int other = (int)usub_sat1((uint32_t)oth[k]);
-#else
-            const int other = s01 - vmed3_i32(mg[k], min0, min1);
-#endif
             const int sg = (signs ^ inp[k]) >> 31;
             const int out = (other ^ sg) - sg;
             const int nl = sat_sum_u8(inp[k], out);
@@ -380,10 +359,8 @@ __global__ __launch_bounds__(kThreads, 6) void ldpc_layered_pr_kernel(
         if (finished && other_flags[1]) break;
 
         // ---- one update sweep ----
-#if DVBS2_PR_SADDR
         finished = __builtin_amdgcn_readfirstlane((int)finished) != 0; // (uniform over the frame; read from LDS above)
         const uint32_t roff = (uint32_t)row * 4u;
-#endif
         const bool work = !finished;
         uint32_t pre1[RW], pre2[RW]; // records of the next two layers for this row
         int carry = 0x80;
@@ -437,26 +414,14 @@ __global__ __launch_bounds__(kThreads, 6) void ldpc_layered_pr_kernel(
             const int own_in = (int)(pre1[PW] >> 24); // top byte of record i+1 = P[i] (not used by the last layer)
             if constexpr (kDeferStore) {
                 asm volatile("" ::: "memory"); __builtin_amdgcn_s_waitcnt(0x0f70); asm volatile("" ::: "memory"); // vmcnt(0), on every path
-#if DVBS2_PR_SADDR
                 if (pend_on) { // (pend_on: work && i > 0, the record of layer i - 1)
 #pragma unroll
                     for (int w = 0; w < RW; w++) pr_st(mp - (RW - w) * kMsgStride, roff, pend[w]);
                 }
-#else
-                if (pend_on) {
-                    uint32_t* pp = msg_base + (size_t)pend_i * RW * kMsgStride;
-#pragma unroll
-                    for (int w = 0; w < RW; w++) pp[w * kMsgStride + row] = pend[w];
-                }
-#endif
             }
             if (work && i + 2 < q) {
 #pragma unroll
-#if DVBS2_PR_SADDR
                 for (int w = 0; w < RW; w++) pre2[w] = pr_ld(mp + (2 * RW + w) * kMsgStride, roff);
-#else
-                for (int w = 0; w < RW; w++) pre2[w] = mp[(2 * RW + w) * kMsgStride + row];
-#endif
             }
             uint32_t y6 = 0;
             bool have_y6 = false;
