@@ -89,6 +89,7 @@ private:
     bool soft_bar_ = false;       // per-frame software barriers (high-degree tables without hazard layers)
     int fallback_rounds_ = 0;
     bool pr_w1_ = false;          // parity-in-records kernel with one-dword records (check degree <= 4)
+    bool pr_v2_ = false;          // parity-in-records kernel with packed nodes in the regular middle layers (two-dword records, per-wave sweep records)
     bool hz2_ = false;            // the build with the heavy-hazard paths (ldpc_kernel.hpp, HZ2)
     bool solo_ = false;           // one frame per workgroup, complementary wave roles per CU (ldpc_kernel.hpp)
     int* d_cu_slots_ = nullptr;   // per-CU pattern counters of the solo kernels

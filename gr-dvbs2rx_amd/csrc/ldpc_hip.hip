@@ -286,6 +286,12 @@ LdpcDecoderHip::LdpcDecoderHip(const LdpcTableDesc* table, int out_bits_message,
     pr_w1_ = pr_ && degmax <= 4;
     if (const char* e = getenv("DVBS2_PR_W1")) pr_w1_ = pr_ && degmax <= 4 && atoi(e) != 0;
     if (pr_w1_) words_per_check_ = 1;
+    // packed nodes (check_node_v2_pr) in the regular middle layers of the two-dword-record kernel: per-wave sweep records as for the classic packed builds
+    // Measured (MI355X, interleaved A/B x 3, gpurun_out/r6u, r6w): short 2/5, 1/2, S2X short 26/45 / medium 1/3 +3.0 ... +3.8 %, short 1/3 +0.7 %; on NORMAL frames forced onto
+    // this kernel (DVBS2_PR=1) B4 +2.1 % and S2X 9/20 +2.5 % on never-converging input -- and B4 9 % SLOWER at its operating point (Es/N0 2.0 dB: 353 -> 323 k frames/s;
+    // this kernel's full syndrome test fetches the parity signs from the records): short / medium frames by rule, normal frames stay with the classic builds.
+    pr_v2_ = pr_ && !pr_w1_ && sched_.N < 64800;
+    if (const char* e = getenv("DVBS2_PR_V2")) pr_v2_ = pr_ && !pr_w1_ && atoi(e) != 0;
     if (pr_) for (int i = 0; i < sched_.q; i++) hr[(size_t)i * RS] &= ~(1u << 12); // that kernel has no lane chain (80 VGPRs)
     if (pr_) {
         const int q = sched_.q;
@@ -366,7 +372,8 @@ LdpcDecoderHip::LdpcDecoderHip(const LdpcTableDesc* table, int out_bits_message,
             // ordered entries keep their record order in the first fix slots, the mixed regular entries follow; dmax / 2 fix slots in all
             const int ncv = layer_nc[i];
             const bool v2p = v2 && v2p_on && v2p_class(dmax_) && L.block < 360 && !chain2 && (ncv == 2 || ncv == 4 || ncv == 8) && (int)L.cnt >= ncv;
-            if (L.block < 360 ? !(chain2 || v2p) : !v2) continue;
+            // (parity-in-records: the last layer keeps its plain node, like layer 0; check_node_v2_pr exists for the degrees 5 .. 7)
+            if (L.block < 360 ? !(chain2 || v2p) : !(v2 || (pr_v2_ && i != sched_.q - 1 && L.cnt + 2 >= 5))) continue;
             const int lo = 64 * w, hi = std::min(64 * w + 63, 359);
             std::vector<int> mixed, plain;
             auto is_mixed = [&](int k) { const int thr = 360 - (int)sched_.entries[L.entry_off + k].rot; return lo < thr && thr <= hi; };
@@ -469,7 +476,7 @@ LdpcDecoderHip::LdpcDecoderHip(const LdpcTableDesc* table, int out_bits_message,
         if (!slots) { err_ = e; return; }
         d_cu_slots_ = slots;
     }
-    kname_ = pr_ ? std::string(pr_w1_ ? "ldpc_layered_pr_kernel<w1>" : "ldpc_layered_pr_kernel") : "ldpc_layered_kernel<" + std::to_string(dmax_) + (dense_ ? ", dense>" : std::string(v2_ ? ", packed" : chain_plain_ ? ", chain" : "") + (solo_ ? ", solo>" : hz2_ ? ", hz2>" : soft_bar_ ? ", soft>" : ">"));
+    kname_ = pr_ ? std::string(pr_w1_ ? "ldpc_layered_pr_kernel<w1>" : pr_v2_ ? "ldpc_layered_pr_kernel<packed>" : "ldpc_layered_pr_kernel") : "ldpc_layered_kernel<" + std::to_string(dmax_) + (dense_ ? ", dense>" : std::string(v2_ ? ", packed" : chain_plain_ ? ", chain" : "") + (solo_ ? ", solo>" : hz2_ ? ", hz2>" : soft_bar_ ? ", soft>" : ">"));
     lds_bytes_ = pr_ ? pr_lds_bytes(sched_.N, sched_.K, pr_shared_sv_) : 2 * half_lds_bytes(sched_.N);
     if (const char* e = getenv("DVBS2_LDS_PAD")) lds_bytes_ += (size_t)atoi(e); // occupancy experiments only
     if (pr_) HIP_OK(ldpc_pr_prepare(lds_bytes_));
@@ -504,7 +511,7 @@ void LdpcDecoderHip::launch_sweep(const int8_t* in, bool resume, int stop_on_goo
     if (gs) (void)hipMemsetAsync(d_gsync_ + frame_base, 0, (size_t)n_frames * 4, stream); // (frame_base is a multiple of the group size: enqueue())
     la.n_frames = n_frames; la.N = sched_.N; la.K = sched_.K; la.q = sched_.q; la.cap = max_trials; la.stop_on_good = stop_on_good | (soft_bar_ ? 2 : 0) | (gs ? 4 : 0) | (pr_ && pr_shared_sv_ ? 8 : 0);
     la.tdbg = d_tdbg_; la.lds_bytes = solo_ ? half_lds_bytes(sched_.N) : lds_bytes_; la.stream = stream; la.dense = dense_;
-    la.v2 = pr_ ? pr_w1_ : v2_; la.solo = solo_; la.chain = chain_plain_; la.hz2 = hz2_; la.soft = soft_bar_; la.cu_slots = d_cu_slots_;
+    la.v2 = pr_ ? pr_w1_ : v2_; la.solo = solo_; la.chain = pr_ ? pr_v2_ : chain_plain_; la.hz2 = hz2_; la.soft = soft_bar_; la.cu_slots = d_cu_slots_;
     la.dm = DemapFused{};
     if (dm && !resume) la.dm = *dm;
     if (pr_) ldpc_pr_launch(la);

@@ -140,6 +140,79 @@ __device__ __forceinline__ uint32_t check_node_pr6(uint8_t* __restrict__ lds, co
     return y | ((uint32_t)spare << 24);
 }
 
+// check_node_v2 (ldpc_kernel.hpp: pairs of edges in the 16-bit halves of a register, one-add addresses from the wave's record) for the regular middle
+// layers of the two-dword-record kernel (round 6, last session). Differences: the two parity entries DEG-2 (own) and DEG-1 (previous) come from and go
+// back to registers (own_in / carry / byte 3 of word 1), LDS holds offset-binary bytes (the plain nodes of layer 0, the last layer and the hazard layers
+// share it), and word 1's byte 3 is the parity LLR -- at degree 7 that is where the pad half of pair 3 would keep its (always zero) message, so the pair is
+// unpacked without it. Messages of such a (layer, wave) are two's complement bytes in pair order (private to the layer, as in the classic kernel).
+template <int DEG>
+__device__ __forceinline__ void check_node_v2_pr(const uint32_t* ent /*record words 4..: window offsets of the data entries [8], then (mask lo, mask hi)[2]*/,
+                                                 int jjb, const uint32_t* mw, uint32_t* nm, int own_in, int* carry)
+{
+    static_assert(DEG >= 5 && DEG <= 7, "two-dword records of degree 5 .. 7");
+    constexpr int DMAX = 8, ND = DEG - 2, NP = (DEG + 1) / 2;
+    constexpr int NFIX = v2_nfix(DMAX) < ND ? v2_nfix(DMAX) : ND;
+    constexpr bool ODD = (DEG & 1) != 0;
+    __builtin_amdgcn_s_setprio(0);
+    int ad[ND];
+#pragma unroll
+    for (int k = 0; k < ND; k++) ad[k] = jjb + (int)ent[k];
+#pragma unroll
+    for (int k = 0; k < NFIX; k++) ad[k] = fix_wrap(ad[k], ent[DMAX + 2 * k], ent[DMAX + 2 * k + 1]);
+    int Lb[DEG];
+#pragma unroll
+    for (int k = 0; k < ND; k++) Lb[k] = lds_rd(ad[k]);
+    Lb[DEG - 2] = own_in; Lb[DEG - 1] = *carry;
+    v2s16 d[NP], a[NP];
+    uint32_t sx = 0;
+#pragma unroll
+    for (int j = 0; j < NP; j++) {
+        uint32_t M = msg_pair16<false>(mw, j);
+        if (ODD && j == NP - 1 && (j & 1)) M &= 0x0000ff00u; // degree 7: byte 3 of word 1 is the parity LLR, not the pad's message
+        const uint32_t hi = (ODD && j == NP - 1) ? 0x80u : (uint32_t)Lb[2 * j + 1];
+        const uint32_t L = __builtin_amdgcn_perm(hi, (uint32_t)Lb[2 * j], 0x040c000cu) ^ kObPair<false>;
+        d[j] = __builtin_elementwise_sub_sat(as_v2s(L), as_v2s(M));
+        sx ^= as_u32(d[j]);
+        a[j] = __builtin_elementwise_max(d[j], __builtin_elementwise_sub_sat(as_v2s(0u), d[j]));
+    }
+    __builtin_amdgcn_s_setprio(1);
+    int mg[DEG];
+#pragma unroll
+    for (int k = 0; k < DEG; k++) mg[k] = (k & 1) ? (int)(as_u32(a[k >> 1]) >> 16) : (int)(as_u32(a[k >> 1]) & 0xffffu);
+    int n0, n1;
+    two_smallest<DEG>(mg, n0, n1);
+    n0 &= 0x7f00; n1 &= 0x7f00;
+    const int n0m = (int)__builtin_elementwise_sub_sat((uint32_t)n0, 256u), n1m = (int)__builtin_elementwise_sub_sat((uint32_t)n1, 256u);
+    const int B0 = n0, B1 = n0 + n1m - n0m, T = n1m + n0;
+    const v2s16 B0p = { (short)B0, (short)B0 }, B1p = { (short)B1, (short)B1 }, Tp = { (short)T, (short)T };
+    const uint32_t tm = (uint32_t)((int)(sx ^ (sx << 16)) >> 31);
+    uint32_t R[NP];
+    int spare = 0x80;
+#pragma unroll
+    for (int j = 0; j < NP; j++) {
+        const v2s16 c = __builtin_elementwise_min(__builtin_elementwise_max(a[j], B0p), B1p);
+        const v2s16 other = Tp - c;
+        const v2s16 sg = as_v2s(as_u32(d[j]) ^ tm) >> (v2s16){ 15, 15 };
+        const v2s16 out = as_v2s(as_u32(other) ^ as_u32(sg)) - sg;
+        const uint32_t nl = (as_u32(__builtin_elementwise_add_sat(d[j], out)) ^ kObPair<false>) >> 8; // bits 7:0 / 23:16: the new LLR bytes of the pair
+        constexpr int kOwn = DEG - 2, kPrev = DEG - 1;
+        const int e0 = 2 * j, e1 = 2 * j + 1;
+        if (e0 < ND) lds_wr(ad[e0 < ND ? e0 : 0], (int)nl);
+        else if (e0 == kOwn) *carry = (int)(nl & 0xffu);
+        else if (e0 == kPrev) spare = (int)(nl & 0xffu);
+        if (!(ODD && j == NP - 1)) {
+            if (e1 < ND) lds_wr_hi(ad[e1 < ND ? e1 : 0], nl);
+            else if (e1 == kOwn) *carry = (int)((nl >> 16) & 0xffu);
+            else if (e1 == kPrev) spare = (int)((nl >> 16) & 0xffu);
+        }
+        R[j] = as_u32(__builtin_elementwise_min(__builtin_elementwise_max(out, (v2s16){ -32 * 256, -32 * 256 }), (v2s16){ 31 * 256, 31 * 256 }));
+    }
+    __builtin_amdgcn_s_setprio(3);
+    if (ODD) R[NP - 1] &= 0x0000ffffu;
+    msg_pack16<false, NP, 2>(R, nm);
+    nm[1] = (nm[1] & 0x00ffffffu) | ((uint32_t)spare << 24);
+}
+
 // Step 1 of the full syndrome test of the parity-in-records kernel: sign bits / zero test of all N LLRs of one frame, 360 per group, into the
 // frame's sign-vector area. A function of its own, NOT inlined: the full test runs rarely on never-converging input, and inlined its chunk of
 // loads cost the sweep of every table 1-3 % through register allocation (round 5; the same rule as syndrome_sign_vectors in ldpc_kernel.hpp).
@@ -180,9 +253,9 @@ __device__ __attribute__((noinline)) unsigned long long pr_sign_vectors(const ld
 // record word at (uniform word pointer) + (per-lane BYTE offset, loop invariant): the form the global instructions take a scalar base for
 __device__ __forceinline__ uint32_t pr_ld(const uint32_t* sbase, uint32_t boff) { return *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(sbase) + boff); }
 __device__ __forceinline__ void pr_st(uint32_t* sbase, uint32_t boff, uint32_t v) { *reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(sbase) + boff) = v; }
-template <bool W1>
+template <bool W1, bool V2 = false /*packed nodes in the regular middle layers (per-wave records, two-dword records only)*/>
 __global__ __launch_bounds__(kThreads, 6) void ldpc_layered_pr_kernel(
-    const uint32_t* __restrict__ recs, const int8_t* __restrict__ llr_in, uint8_t* __restrict__ state,
+    const uint32_t* __restrict__ recs, const uint32_t* __restrict__ wrecs, const int8_t* __restrict__ llr_in, uint8_t* __restrict__ state,
     uint32_t* __restrict__ msgs, int* __restrict__ iters, int* __restrict__ good, const int* __restrict__ target,
     int n_frames, int N, int K, int q, int cap, int stop_on_good /*bit 0: stop at a good syndrome, bit 2: group-synchronous stop (ldpc_kernel.hpp, group_decide), bit 3: one sign-vector area per workgroup*/)
 {
@@ -193,7 +266,10 @@ __global__ __launch_bounds__(kThreads, 6) void ldpc_layered_pr_kernel(
         if (!ta && !tb) return;
     }
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_all[];
+    static_assert(!(W1 && V2), "packed nodes: two-dword records");
     constexpr int DMAX = 8, RS = rec_stride(DMAX), MW = 2 /*words the check nodes take*/, RW = W1 ? 1 : 2 /*words per stored record*/;
+    constexpr int RSW = rec_stride_wave(DMAX);
+    constexpr int LS = V2 ? 6 * RSW : RS; // dwords from one layer's sweep record to the next (V2: this wave's records, wrecs[(layer * 6 + wave) * RSW])
     constexpr int PW = RW - 1; // word of a record whose top byte is the parity LLR
     const int half = __builtin_amdgcn_readfirstlane(threadIdx.x >= kHalf ? 1 : 0);
     const int tid = threadIdx.x - half * kHalf;
@@ -216,6 +292,8 @@ __global__ __launch_bounds__(kThreads, 6) void ldpc_layered_pr_kernel(
     const int NGD = K / kM, NG = N / kM;
     const bool active = tid < kM;
     const int row = tid < kM ? tid : kM - 1; // threads 360..383 mirror row 359 (ldpc_kernel.hpp)
+    const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6); // wave of the frame, known to be uniform
+    const uint32_t* srec = V2 ? wrecs + (size_t)wave_u * RSW : recs; // the sweep's records: per (layer, wave) with packed nodes, else per layer
 
     uint32_t* msg_base = msgs + (size_t)(have_frame ? f : 0) * q * RW * kMsgStride;
     int it = 0, tgt = 0;
@@ -243,8 +321,10 @@ __global__ __launch_bounds__(kThreads, 6) void ldpc_layered_pr_kernel(
                 msg_base[1 * kMsgStride + tid] = 0x80808080u;
                 for (int i = 0; i < q - 1; i++) {
                     const uint32_t b = (uint8_t)pj[i] ^ 0x80u;
-                    msg_base[((i + 1) * MW + 0) * kMsgStride + tid] = 0x80808080u;
-                    msg_base[((i + 1) * MW + 1) * kMsgStride + tid] = 0x00808080u | (b << 24);
+                    // zero messages in the format of the (layer, wave) that owns the record: offset binary, or two's complement for a packed node
+                    const uint32_t z = (V2 && ((srec[(size_t)(i + 1) * LS] >> 13) & 1u)) ? 0u : 0x80808080u;
+                    msg_base[((i + 1) * MW + 0) * kMsgStride + tid] = z;
+                    msg_base[((i + 1) * MW + 1) * kMsgStride + tid] = (z & 0x00ffffffu) | (b << 24);
                 }
                 }
                 lds[K + tid] = (uint8_t)pj[q - 1] ^ 0x80u;
@@ -368,10 +448,10 @@ __global__ __launch_bounds__(kThreads, 6) void ldpc_layered_pr_kernel(
 #pragma unroll
             for (int w = 0; w < RW; w++) { pre1[w] = msg_base[w * kMsgStride + row]; pre2[w] = msg_base[(RW + w) * kMsgStride + row]; }
         }
-        uint32_t nhdr = recs[0];
+        uint32_t nhdr = srec[0];
         uint32_t nent[2 * DMAX];
 #pragma unroll
-        for (int k = 0; k < 2 * DMAX; k++) nent[k] = recs[4 + k];
+        for (int k = 0; k < 2 * DMAX; k++) nent[k] = srec[4 + k];
         // The record a layer produces is STORED at the head of the next layer, behind an explicit s_waitcnt vmcnt(0) (see
         // DVBS2_WAIT_BEFORE_STORE in ldpc_kernel.hpp: the compiler waits for the prefetched record with vmcnt(0) at the head of a layer,
         // i.e. right behind the store the previous layer has just issued; stored here instead, everything that wait covers is a layer old).
@@ -389,7 +469,7 @@ __global__ __launch_bounds__(kThreads, 6) void ldpc_layered_pr_kernel(
 #pragma unroll
             for (int k = 0; k < 2 * DMAX; k++) ent[k] = nent[k];
             {
-                const uint32_t* nrec = recs + (size_t)(i + 1 < q ? i + 1 : 0) * RS;
+                const uint32_t* nrec = srec + (size_t)(i + 1 < q ? i + 1 : 0) * LS;
                 nhdr = nrec[0];
 #pragma unroll
                 for (int k = 0; k < 2 * DMAX; k++) nent[k] = nrec[4 + k];
@@ -433,7 +513,16 @@ __global__ __launch_bounds__(kThreads, 6) void ldpc_layered_pr_kernel(
                         else { if (first_layer) y6 = check_node_pr6<3, true, false>(lds_all, ent, jj, lb, x6, own_in, &carry); else if (last_layer) y6 = check_node_pr6<3, false, true>(lds_all, ent, jj, lb, x6, own_in, &carry); else y6 = check_node_pr6<3, false, false>(lds_all, ent, jj, lb, x6, own_in, &carry); }
                     }
                 } else {
-                    if (work) { DVBS2_PR_SWITCH }
+                    if (work) {
+                        if (V2 && ((hdr >> 13) & 1u)) { // this wave's record is in the packed node's format (a regular layer that is neither the first nor the last)
+                            switch (deg) {
+                                case 5: check_node_v2_pr<5>(ent, jj + lb, mw, nm, own_in, &carry); break;
+                                case 6: check_node_v2_pr<6>(ent, jj + lb, mw, nm, own_in, &carry); break;
+                                case 7: check_node_v2_pr<7>(ent, jj + lb, mw, nm, own_in, &carry); break;
+                                default: break;
+                            }
+                        } else { DVBS2_PR_SWITCH }
+                    }
                 }
             } else {
                 if constexpr (W1) { if (work) pr_w1_expand(x6, mw); }
@@ -487,6 +576,7 @@ hipError_t ldpc_pr_prepare(size_t lds_bytes)
 {
     hipError_t e = hipFuncSetAttribute((const void*)ldpc_layered_pr_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ldpc_layered_pr_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ldpc_layered_pr_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e == hipSuccess && getenv("DVBS2_OCC")) {
         int nb = -1;
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, ldpc_layered_pr_kernel<false>, kThreads, lds_bytes);
@@ -496,9 +586,12 @@ hipError_t ldpc_pr_prepare(size_t lds_bytes)
 }
 void ldpc_pr_launch(const LdpcLaunch& a)
 {
-    if (a.v2) hipLaunchKernelGGL(ldpc_layered_pr_kernel<true>, dim3((a.n_frames + 1) / 2), dim3(kThreads), a.lds_bytes, a.stream, a.recs, a.llr_in, a.state, a.msgs,
+    if (a.v2) hipLaunchKernelGGL(ldpc_layered_pr_kernel<true>, dim3((a.n_frames + 1) / 2), dim3(kThreads), a.lds_bytes, a.stream, a.recs, a.wrecs, a.llr_in, a.state, a.msgs,
                                  a.iters, a.good, a.target, a.n_frames, a.N, a.K, a.q, a.cap, a.stop_on_good);
-    else hipLaunchKernelGGL(ldpc_layered_pr_kernel<false>, dim3((a.n_frames + 1) / 2), dim3(kThreads), a.lds_bytes, a.stream, a.recs, a.llr_in, a.state, a.msgs,
+    else if (a.chain /*packed nodes (LdpcLaunch::chain is the classic kernel's flag; this kernel has no chain node)*/)
+        hipLaunchKernelGGL((ldpc_layered_pr_kernel<false, true>), dim3((a.n_frames + 1) / 2), dim3(kThreads), a.lds_bytes, a.stream, a.recs, a.wrecs, a.llr_in, a.state, a.msgs,
+                           a.iters, a.good, a.target, a.n_frames, a.N, a.K, a.q, a.cap, a.stop_on_good);
+    else hipLaunchKernelGGL(ldpc_layered_pr_kernel<false>, dim3((a.n_frames + 1) / 2), dim3(kThreads), a.lds_bytes, a.stream, a.recs, a.wrecs, a.llr_in, a.state, a.msgs,
                             a.iters, a.good, a.target, a.n_frames, a.N, a.K, a.q, a.cap, a.stop_on_good);
 }
 #endif

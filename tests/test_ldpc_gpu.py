@@ -65,6 +65,8 @@ def test_near_threshold_groups(table, amp, sigma, G):
 VARIANTS = {  # every build of the sweep kernel gives the same bits (environment overrides of the per-table policy)
     "policy": {},
     "pr-byte-records": {"DVBS2_PR_W1": "0"},                                                       # parity in records with two-dword records also for degree <= 4
+    "pr-plain": {"DVBS2_PR_V2": "0"},                                                             # the two-dword-record kernel with its plain nodes everywhere
+    "pr-packed": {"DVBS2_PR": "1", "DVBS2_PR_W1": "0", "DVBS2_PR_V2": "1"},                          # parity in records on every eligible table (normal frames too), packed nodes in the regular middle layers
     "classic": {"DVBS2_PR": "0", "DVBS2_DENSE": "0"},                                              # no parity-in-records / dense build
     "plain": {"DVBS2_PR": "0", "DVBS2_DENSE": "0", "DVBS2_HZ2": "0", "DVBS2_V2": "0", "DVBS2_SOLO": "0"},          # byte messages, scalar nodes, pair workgroups
     "packed-pair": {"DVBS2_PR": "0", "DVBS2_DENSE": "0", "DVBS2_HZ2": "0", "DVBS2_V2": "1", "DVBS2_SOLO": "0"},    # packed nodes, six-bit messages, pair workgroups
@@ -257,9 +259,11 @@ def test_kernel_variant_policy(monkeypatch):
     assert name("S2_TABLE_B7") == expect("S2_TABLE_B7", 16)
     assert name("S2_TABLE_B11") == expect("S2_TABLE_B11", 32)
     assert name("S2X_TABLE_B9") == expect("S2X_TABLE_B9", 16)
-    assert name("S2_TABLE_C2") == "ldpc_layered_pr_kernel"        # short / medium frames of degree <= 7: parity in records
+    assert name("S2_TABLE_C2") == "ldpc_layered_pr_kernel<packed>"  # short / medium frames of degree <= 7: parity in records, packed nodes in the regular middle layers (round 6)
+    assert name("S2_TABLE_C2", DVBS2_PR_V2="0") == "ldpc_layered_pr_kernel"
     assert name("S2_TABLE_C1") == "ldpc_layered_pr_kernel<w1>"    # ... of degree <= 4: one-dword records (6-bit messages + parity byte)
-    assert name("S2_TABLE_C1", DVBS2_PR_W1="0") == "ldpc_layered_pr_kernel"
+    assert name("S2_TABLE_C1", DVBS2_PR_W1="0") == "ldpc_layered_pr_kernel<packed>"  # (two-dword records: the packed build, whose packed nodes start at degree 5 -- none of this table's layers)
+    assert name("S2_TABLE_C1", DVBS2_PR_W1="0", DVBS2_PR_V2="0") == "ldpc_layered_pr_kernel"
     assert name("S2X_TABLE_C9") == "ldpc_layered_pr_kernel<w1>"   # medium frame
     assert name("S2_TABLE_C5") == "ldpc_layered_kernel<12, dense>"  # short 3/5: 16 of 18 layers are hazard layers
     assert name("S2_TABLE_C5", DVBS2_DENSE="0", DVBS2_V2="0", DVBS2_SOLO="0") == "ldpc_layered_kernel<12>"

@@ -22,7 +22,8 @@ bench = json.loads(line)
 def short(rocname):
     """rocprofv3 name -> dvbs2_ldpc_kernel_name() form"""
     if "ldpc_layered_pr_kernel" in rocname:
-        return "ldpc_layered_pr_kernel<w1>" if "ldpc_layered_pr_kernel<true>" in rocname else "ldpc_layered_pr_kernel"
+        m = re.search(r"ldpc_layered_pr_kernel<(\w+)(?:, (\w+))?>", rocname)  # <W1, V2>
+        return "ldpc_layered_pr_kernel<w1>" if m and m.group(1) == "true" else "ldpc_layered_pr_kernel<packed>" if m and m.group(2) == "true" else "ldpc_layered_pr_kernel"
     m = re.search(r"ldpc_layered_kernel<(\d+), (\w+), (\d+), (\w+), (\w+), (\w+), (\w+), (\w+)>", rocname)
     if not m:
         return None

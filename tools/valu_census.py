@@ -49,9 +49,9 @@ def classify(op):
 
 
 def short(mangled):
-    m = re.search(r"ldpc_layered_pr_kernelILb([01])E", mangled)
+    m = re.search(r"ldpc_layered_pr_kernelILb([01])ELb([01])E", mangled)  # <W1, V2>
     if m:
-        return "ldpc_layered_pr_kernel<w1>" if m.group(1) == "1" else "ldpc_layered_pr_kernel"
+        return "ldpc_layered_pr_kernel<w1>" if m.group(1) == "1" else "ldpc_layered_pr_kernel<packed>" if m.group(2) == "1" else "ldpc_layered_pr_kernel"
     m = re.search(r"ldpc_layered_kernelILi(\d+)ELb([01])ELi(\d+)ELb([01])ELb([01])ELb([01])ELb([01])ELb([01])E", mangled)
     if not m:
         return None
