@@ -511,7 +511,7 @@ void LdpcDecoderHip::launch_sweep(const int8_t* in, bool resume, int stop_on_goo
     if (gs) (void)hipMemsetAsync(d_gsync_ + frame_base, 0, (size_t)n_frames * 4, stream); // (frame_base is a multiple of the group size: enqueue())
     la.n_frames = n_frames; la.N = sched_.N; la.K = sched_.K; la.q = sched_.q; la.cap = max_trials; la.stop_on_good = stop_on_good | (soft_bar_ ? 2 : 0) | (gs ? 4 : 0) | (pr_ && pr_shared_sv_ ? 8 : 0);
     la.tdbg = d_tdbg_; la.lds_bytes = solo_ ? half_lds_bytes(sched_.N) : lds_bytes_; la.stream = stream; la.dense = dense_;
-    la.v2 = pr_ ? pr_w1_ : v2_; la.solo = solo_; la.chain = pr_ ? pr_v2_ : chain_plain_; la.hz2 = hz2_; la.soft = soft_bar_; la.cu_slots = d_cu_slots_;
+    la.v2 = pr_ ? pr_w1_ : v2_; la.solo = solo_; la.chain = chain_plain_; la.pr_packed = pr_ && pr_v2_; la.hz2 = hz2_; la.soft = soft_bar_; la.cu_slots = d_cu_slots_;
     la.dm = DemapFused{};
     if (dm && !resume) la.dm = *dm;
     if (pr_) ldpc_pr_launch(la);

@@ -2026,6 +2026,7 @@ struct LdpcLaunch {
     bool chain; // plain build + packed chain node (kChainBuilt; ignored with v2, which has it anyway)
     bool hz2;   // plain pair build with the heavy-hazard paths (kHz2Built)
     bool soft;  // pair build (plain or packed) with software frame barriers (kSoftBuilt)
+    bool pr_packed = false; // parity-in-records kernel (ldpc_kernel_pr.hpp): packed nodes in the regular middle layers (two-dword records; v2 there = one-dword records)
     int* cu_slots;
 };
 template <int DMAX> hipError_t ldpc_variant_prepare(size_t pair_lds_bytes, size_t solo_lds_bytes);

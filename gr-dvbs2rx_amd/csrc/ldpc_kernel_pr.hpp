@@ -588,7 +588,7 @@ void ldpc_pr_launch(const LdpcLaunch& a)
 {
     if (a.v2) hipLaunchKernelGGL(ldpc_layered_pr_kernel<true>, dim3((a.n_frames + 1) / 2), dim3(kThreads), a.lds_bytes, a.stream, a.recs, a.wrecs, a.llr_in, a.state, a.msgs,
                                  a.iters, a.good, a.target, a.n_frames, a.N, a.K, a.q, a.cap, a.stop_on_good);
-    else if (a.chain /*packed nodes (LdpcLaunch::chain is the classic kernel's flag; this kernel has no chain node)*/)
+    else if (a.pr_packed)
         hipLaunchKernelGGL((ldpc_layered_pr_kernel<false, true>), dim3((a.n_frames + 1) / 2), dim3(kThreads), a.lds_bytes, a.stream, a.recs, a.wrecs, a.llr_in, a.state, a.msgs,
                            a.iters, a.good, a.target, a.n_frames, a.N, a.K, a.q, a.cap, a.stop_on_good);
     else hipLaunchKernelGGL(ldpc_layered_pr_kernel<false>, dim3((a.n_frames + 1) / 2), dim3(kThreads), a.lds_bytes, a.stream, a.recs, a.wrecs, a.llr_in, a.state, a.msgs,
